@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- north-star benchmark: Mrays/s of a 4096x4096 Kerr (a = 0.9) shadow render,
+fixed-step RK4 in float32, on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole frame: every rank renders its block-cyclic share of the pixel rows
+(prologue + integrate + epilogue kernels of libltrace_hip.so, launched on torch's current
+stream), then the RGBA8 framebuffer is gathered to rank 0 over RCCL and un-permuted there.
+The frame is fixed as N grows, so scaling is "strong".  Everything the timed region reads is
+already resident in HBM; no per-ray input exists (pixel -> ray happens in the prologue kernel).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the integrate kernel against the FP32 VALU
+peak with the reference's as-written flop counts; `cpu_baseline` is the oracle
+(CPU port of the reference algorithm, float64, OpenMP) timed on this host on a strided
+subsample of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "light-path-tracer_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import ltrace  # noqa: E402
+
+# As-written flop counts of the reference
+F_RK4_STEP = 4 * 188 + 80     # 832 per RK4 step   (metrics.py:221-323)
+F_KERR_FIXED = 95 + 72        # 167 per ray        (metrics.py:148-218, :363-416)
+F_SCHW_STEP = 54
+F_SCHW_FIXED = 45
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=4096, help="frame is size x size")
+    ap.add_argument("--a", type=float, default=0.9)
+    ap.add_argument("--r-obs", type=float, default=50.0)
+    ap.add_argument("--metric", choices=["kerr", "schwarzschild"], default="kerr")
+    ap.add_argument("--schedule", choices=["direct", "queue"], default=os.environ.get("LT_SCHEDULE", "direct"))
+    ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--integrator", choices=["rk4", "dp45"], default="rk4")
+    ap.add_argument("--row-block", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg")
+    ap.add_argument("--background", action="store_true", help="image_lens workload: lens a synthetic background")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, fov):
+    """Oracle (CPU port of the reference's RK4 tracer, float64, all cores) on a strided subsample of
+    the benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame
+    of the same camera."""
+    from oracle import oracle
+    kind = args.metric
+    t0 = time.perf_counter()
+    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, integrator=args.integrator)
+    dt = time.perf_counter() - t0          # calibration (includes thread spin-up)
+    rate = 256 * 256 / dt
+    stride = 2
+    while stride < args.size // 256 and (args.size // stride) ** 2 / rate > args.cpu_seconds:
+        stride *= 2
+    n = args.size // stride
+    t0 = time.perf_counter()
+    r = oracle.lookup(kind, 1.0, args.a, args.r_obs, n, n, fov, fov, integrator=args.integrator)
+    dt = time.perf_counter() - t0
+    return {"value": round(n * n / dt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.num_threads(),
+            "kind": "port",
+            "sample": f"{n}x{n} rays = every {stride}th pixel (x and y) of the {args.size}x{args.size} frame, "
+                      f"oracle {args.integrator} float64 + OpenMP, {dt:.1f} s",
+            "mean_rhs_evals_per_ray": round(float(r["evals"].mean()), 1)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    size = args.size
+    fov = float(np.radians(40.0))
+    cam = ltrace.Camera(size, size, fov, fov, 0.0, 0.0, args.r_obs, np.pi / 2)
+    met = ltrace.Metric(ltrace.METRIC_KERR if args.metric == "kerr" else ltrace.METRIC_SCHWARZSCHILD, 0, 1.0,
+                        args.a if args.metric == "kerr" else 0.0)
+    rb = args.row_block
+    rows = ltrace.local_rows(size, rb, world, rank)
+    rows_max = max(ltrace.local_rows(size, rb, world, p) for p in range(world))
+
+    # device buffers (torch owns the memory; the library only sees raw pointers)
+    d_rgba = torch.empty((rows_max, size, 4), dtype=torch.uint8, device=dev)
+    d_fa = torch.empty((rows_max, size), dtype=torch.float32, device=dev)
+    d_w = torch.empty((rows_max, size), dtype=torch.int16, device=dev)
+    d_stats = torch.zeros(ltrace.STAT_WORDS, dtype=torch.int64, device=dev)
+    d_bg = None
+    if args.background:
+        g = torch.Generator(device="cpu").manual_seed(0)
+        d_bg = (torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8).to(torch.float32) / 255.0).to(dev)
+    full = torch.empty((size, size, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    gather_list = [torch.empty_like(d_rgba) for _ in range(world)] if (rank == 0 and world > 1) else None
+
+    stream = torch.cuda.current_stream(dev)
+    opts = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
+                               row_block=rb, n_parts=world, part=rank, timing=1)
+    opts.stream = stream.cuda_stream
+
+    def step():
+        ltrace.render_dev(cam, met, opts, d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
+                          d_fa=d_fa.data_ptr(), d_w=d_w.data_ptr(), d_rgba=d_rgba.data_ptr(),
+                          d_stats=d_stats.data_ptr())
+        if world > 1:
+            dist.gather(d_rgba, gather_list, dst=0)
+            if rank == 0:
+                for p in range(world):
+                    ltrace.scatter_rows_dev(gather_list[p].data_ptr(), full.data_ptr(), size, size, 4, rb, world, p,
+                                            stream.cuda_stream)
+        # N = 1: the partition is the whole frame, already in row order in d_rgba
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ltrace.timing_collect()            # drop warm-up events
+    d_stats.zero_()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = ltrace.timing_collect()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    counters = d_stats.clone()
+    kern = torch.tensor([tm["prologue_ms"], tm["integrate_ms"], tm["epilogue_ms"]], dtype=torch.float64, device=dev)
+    kern_max = kern.clone()
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kern_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    c = [int(x) for x in counters.tolist()]
+    steps = max(args.steps, 1)
+    rays_per_frame = c[ltrace.STAT_RAYS] // steps
+    rk_steps = c[ltrace.STAT_STEPS] / steps
+    if args.metric == "kerr":
+        flops_frame = rk_steps * F_RK4_STEP + rays_per_frame * F_KERR_FIXED
+    else:
+        flops_frame = rk_steps * F_SCHW_STEP + rays_per_frame * F_SCHW_FIXED
+    ms_per_step = elapsed / steps * 1e3
+    value = rays_per_frame / (elapsed / steps) / 1e6
+
+    if rank == 0:
+        integ_ms = float(kern_max[1].item()) / steps          # slowest rank's average integrate-kernel time
+        achieved = (flops_frame / world) / (integ_ms * 1e-3) / 1e12 if integ_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
+            "config": {"workload": f"{args.metric}_a{args.a}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
+                                   + ("_lensed_background" if args.background else ""),
+                       "rays_per_frame": rays_per_frame, "schedule": args.schedule,
+                       "row_partition": f"block-cyclic {rb} rows x {world}", "gather": "rccl" if world > 1 else "none",
+                       "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
+                       "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
+                       "invalid": c[ltrace.STAT_INVALID] // steps},
+            "roofline": {"bound": "valu_fp32", "kernel": "k_kerr_rk4_" + args.schedule if args.metric == "kerr" else "k_schw_rk4_direct",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "algorithmic_flops_per_launch": int(flops_frame / world),
+                         "avg_launch_ms": round(integ_ms, 4),
+                         "other_kernels_ms": {"prologue": round(float(kern_max[0].item()) / steps, 4),
+                                              "epilogue": round(float(kern_max[2].item()) / steps, 4)}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, fov)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

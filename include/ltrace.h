@@ -1,0 +1,186 @@
+/*
+ * include/ltrace.h -- C-ABI of libltrace_hip.so, the MI355X (gfx950) null-geodesic
+ * ray-tracing library.
+ *
+ * This is the drop-in boundary for the per-pixel backward light-ray integrator of
+ * dhg14n9/Light-path-tracer.  Plain pointers and sizes only; no torch / numpy types.
+ * Every entry point names the reference interface it replaces (file:line in the
+ * reference tree).  The library is HIP-only: with no usable GPU every compute entry
+ * point returns LT_ERR_NO_DEVICE -- there is no CPU fallback.
+ *
+ * Return convention: 0 on success, a negative LT_ERR_* code otherwise;
+ * lt_last_error() returns a thread-local message for the most recent failure.
+ */
+#ifndef LTRACE_H
+#define LTRACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_VERSION 100 /* 0.1.0 */
+
+#define LT_OK 0
+#define LT_ERR_INVALID_ARG (-1)
+#define LT_ERR_HIP (-2)
+#define LT_ERR_NO_DEVICE (-3)
+#define LT_ERR_UNSUPPORTED (-4)
+
+/* metric kinds: metrics.py:735 (Schwarzschild), :840 (Kerr) */
+#define LT_METRIC_SCHWARZSCHILD 0
+#define LT_METRIC_KERR 1
+
+/* integrators: metrics.py:419-567 (DP45, the reference's production Kerr path, float64 only)
+ *              metrics.py:570-658 (radius-banded fixed-step RK4; float32 or float64)
+ * Schwarzschild always uses its orbit-equation RK4, metrics.py:49-117. */
+#define LT_INTEGRATOR_DP45 0
+#define LT_INTEGRATOR_RK4 1
+
+/* ray -> lane scheduling of the integrate kernel */
+#define LT_SCHED_DIRECT 0 /* one work-item per ray, one 8x8 pixel tile per wavefront        */
+#define LT_SCHED_QUEUE 1  /* persistent wavefronts, ray queue, ballot/prefix-sum lane refill */
+
+/* per-ray status, as the reference's integrators return it (metrics.py:69, :125) */
+#define LT_STATUS_ESCAPED 1
+#define LT_STATUS_CAPTURED (-1)
+#define LT_STATUS_INVALID 0
+
+/* Pinhole camera of image_lens.py:133-152 / :193-208 (pixel corners, no +0.5).
+ * psi = (pitch_up, yaw_right) BH offset in radians, image_lens.py:21-61. */
+typedef struct lt_camera {
+    int32_t width, height;
+    double hfov, vfov;
+    double psi_y, psi_x;
+    double r_obs;     /* observer radius (in the same units as M) */
+    double theta_obs; /* observer inclination; the reference only ever uses pi/2 */
+} lt_camera;
+
+typedef struct lt_metric {
+    int32_t kind; /* LT_METRIC_* */
+    int32_t reserved;
+    double M;
+    double a; /* spin, |a| <= M; ignored for Schwarzschild */
+} lt_metric;
+
+typedef struct lt_opts {
+    int32_t integrator;      /* LT_INTEGRATOR_*; Kerr only */
+    int32_t precision;       /* 32 or 64: arithmetic of the integrate kernel */
+    int32_t schedule;        /* LT_SCHED_* */
+    int32_t tb_symmetry;     /* 0 = trace every row; 1 = reference behaviour incl. its
+                                off-by-one mirror (image_lens.py:218-220, :272-276) */
+    int32_t loop_around;     /* render_loop_around of image_lens.py:296-298 */
+    int32_t row_block;       /* rows per block of the block-cyclic row partition (>0) */
+    int32_t n_parts;         /* number of partitions (GPUs); 1 = whole frame */
+    int32_t part;            /* this call renders blocks b with b % n_parts == part */
+    double axis_refine_frac; /* Y_AXIS_REFINE_FRAC = 0.07, image_lens.py:14 */
+    double phi_max;          /* Schwarzschild: 50.0 (metrics.py:833) */
+    double h_max;            /* Schwarzschild: 0.05 (metrics.py:833); Kerr RK4: 1.0 (metrics.py:677) */
+    void *stream;            /* hipStream_t to launch on; NULL = the default stream */
+    int32_t timing;          /* !=0: bracket each kernel with HIP events (lt_timing_collect) */
+    int32_t reserved;
+} lt_opts;
+
+/* Counters produced by the epilogue kernel (one 64-bit word each, device or host). */
+#define LT_STAT_RAYS 0      /* rays integrated */
+#define LT_STAT_STEPS 1     /* sum over rays of integrator steps (RK4 steps / DP45 attempts) */
+#define LT_STAT_RHS_EVALS 2 /* sum over rays of right-hand-side evaluations */
+#define LT_STAT_ESCAPED 3
+#define LT_STAT_CAPTURED 4
+#define LT_STAT_INVALID 5
+#define LT_STAT_WORDS 8
+
+typedef struct lt_stats {
+    uint64_t counters[LT_STAT_WORDS];
+    double prologue_ms, integrate_ms, epilogue_ms; /* HIP-event times of the three kernels */
+} lt_stats;
+
+/* ---- library / device ------------------------------------------------------------- */
+int lt_version(void);
+const char *lt_last_error(void);
+int lt_device_count(void);
+int lt_set_device(int device);
+/* Frees workspaces and events created lazily by the calls below. */
+int lt_shutdown(void);
+void lt_default_opts(lt_opts *o);
+
+/* ---- array-in / array-out twins of the reference batch drivers ---------------------- *
+ * HOST pointers; the library stages H2D / D2H itself.  Same meaning as the reference:   *
+ * out_fa[i] = final_alpha if the ray escaped else NaN; out_w[i] = number of half orbits. */
+
+/* Replaces Schwarzschild.trace_rays_batch (metrics.py:831-833) ->
+ * _trace_rays_batch_schwarzschild (metrics.py:661-668).  precision 32 or 64.
+ * out_status / out_rhs_evals (4 per RK4 step) may be NULL. */
+int lt_trace_batch_schw(double M, double r_obs, const double *alphas, int64_t n, double phi_max,
+                        double h_max, int precision, double *out_fa, int64_t *out_w,
+                        int8_t *out_status, uint32_t *out_rhs_evals);
+
+/* Replaces Kerr.trace_rays_batch (metrics.py:1128-1132) -> _trace_rays_batch_kerr
+ * (metrics.py:671-679).  integrator LT_INTEGRATOR_*, precision 32 or 64 (DP45: 64 only).
+ * axis_refines: one byte per ray (numpy bool), may be NULL (= all false).
+ * out_status / out_rhs_evals may be NULL. */
+int lt_trace_batch_kerr(double M, double a, double r_obs, const double *alphas, const double *thetas,
+                        double theta_obs, double lambda_max, const uint8_t *axis_refines,
+                        int integrator, int precision, int schedule, int64_t n, double *out_fa,
+                        int64_t *out_w, int8_t *out_status, uint32_t *out_rhs_evals);
+
+/* Device probe of the inlined Kerr right-hand side (metrics.py:221-303) for parity tests:
+ * states (n,5) [r, theta, phi, p_r, p_theta], p_phi (n), out (n,5); host pointers, float64 I/O,
+ * evaluated in float32 or float64 on the GPU. */
+int lt_kerr_rhs_probe(double M, double a, const double *states, const double *p_phi, int64_t n,
+                      int precision, double *out);
+
+/* ---- fused frame path ---------------------------------------------------------------- *
+ * Replaces, in one call, build_alpha_lookup (image_lens.py:133-152),                     *
+ * precompute_final_alpha_lookup / _2d (image_lens.py:155-178 / :185-280) and             *
+ * render_lensed_image (image_lens.py:296-397) + the float->RGBA8 step of                 *
+ * mpimg.imsave (image_lens.py:510).  Nothing per-ray crosses PCIe on the way in.         */
+
+/* Number of image rows partition `part` of `n_parts` owns (block-cyclic, blocks of row_block). */
+int64_t lt_local_rows(int32_t height, int32_t row_block, int32_t n_parts, int32_t part);
+/* Global row index of local row `local_row` of that partition. */
+int64_t lt_global_row(int64_t local_row, int32_t row_block, int32_t n_parts, int32_t part);
+
+/* DEVICE pointers (any may be NULL = not wanted), sized for R = lt_local_rows(...) rows:
+ *   d_bg     (H, W, bg_channels) float32 background, the FULL frame on every partition
+ *            (NULL: shadow render, escaped pixels white);  bg_channels 1 or 3
+ *   d_fa     (R, W) float32 final_alpha lookup (NaN unless escaped)
+ *   d_w      (R, W) uint16 winding lookup
+ *   d_status (R, W) int8
+ *   d_steps  (R, W) uint32 integrator steps of the ray
+ *   d_rgb    (R, W, bg_channels or 3) float32 lensed image, as render_lensed_image returns it
+ *   d_rgba   (R, W, 4) uint8, as imsave writes it
+ *   d_stats  LT_STAT_WORDS uint64 counters, ACCUMULATED into (caller zeroes)
+ * Asynchronous on opts->stream. */
+int lt_render_dev(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts,
+                  const float *d_bg, int32_t bg_channels, float *d_fa, uint16_t *d_w,
+                  int8_t *d_status, uint32_t *d_steps, float *d_rgb, uint8_t *d_rgba,
+                  uint64_t *d_stats);
+
+/* Same with HOST pointers (stages the background H2D, results D2H, synchronises);
+ * stats may be NULL. */
+int lt_render(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts,
+              const float *bg, int32_t bg_channels, float *out_fa, uint16_t *out_w,
+              int8_t *out_status, uint32_t *out_steps, float *out_rgb, uint8_t *out_rgba,
+              lt_stats *stats);
+
+/* Scatter a partition's (R, W, elem_bytes) rows into the full (H, W, elem_bytes) frame
+ * (device pointers, async on `stream`): the un-permute step after the multi-GPU gather. */
+int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t height, int32_t width,
+                        int32_t elem_bytes, int32_t row_block, int32_t n_parts, int32_t part,
+                        void *stream);
+
+/* Sum of HIP-event times (ms) of the prologue / integrate / epilogue kernels over all
+ * lt_render_dev calls made with opts->timing != 0 since the last collect; *calls = how many.
+ * Synchronises on the recorded events. */
+int lt_timing_collect(double *prologue_ms, double *integrate_ms, double *epilogue_ms, int32_t *calls);
+
+/* FP32 VALU issue-rate microbenchmark used to calibrate the roofline: runs `iters` dependent-chain
+ * FMA blocks per lane; mode 0 = v_fma_f32, 1 = v_pk_fma_f32.  Returns achieved TFLOP/s in *tflops. */
+int lt_valu_peak_probe(int mode, int iters, double *tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTRACE_H */

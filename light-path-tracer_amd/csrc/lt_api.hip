@@ -1,0 +1,634 @@
+// lt_api.hip -- host side of libltrace_hip.so: the C-ABI declared in include/ltrace.h.
+//
+// Everything here is plumbing around the three kernels of lt_kernels.hpp: build the
+// wave-uniform constant blocks, size the grids, launch on the caller's stream, time with
+// HIP events.  No CPU compute path exists: without a GPU the entry points fail.
+#include "../../include/ltrace.h"
+#include "lt_kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+using namespace lt;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(LT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" int lt_version(void) { return LT_VERSION; }
+extern "C" const char *lt_last_error(void) { return g_err; }
+
+extern "C" int lt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int lt_set_device(int device)
+{
+    if (lt_device_count() <= 0) return fail(LT_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    return LT_OK;
+}
+
+static int require_device()
+{
+    if (lt_device_count() <= 0)
+        return fail(LT_ERR_NO_DEVICE, "libltrace_hip: no HIP device visible (this library has no CPU path)");
+    return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-device context: grow-only workspace for the ray records, timing events
+// ---------------------------------------------------------------------------------------------
+struct EventQuad { hipEvent_t e[4]; };
+
+struct Ctx {
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    std::vector<EventQuad> pending; // recorded, not yet collected
+    std::vector<EventQuad> pool;
+};
+
+static std::mutex g_mu;
+static Ctx g_ctx[64];
+
+static int cur_ctx(Ctx **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(LT_ERR_INVALID_ARG, "device index %d out of range", dev);
+    *out = &g_ctx[dev];
+    return LT_OK;
+}
+
+// Workspace layout: ic[n_q] | fin0[n_q] | fin1[n_q], each a 4-vector of T.
+static int get_workspace(size_t n_q, size_t elem, void **ic, void **fin0, void **fin1)
+{
+    Ctx *c;
+    int rc = cur_ctx(&c);
+    if (rc) return rc;
+    size_t vec = 4 * elem;
+    size_t need = 3 * n_q * vec;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (need > c->ws_bytes) {
+        if (c->ws) {
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipFree(c->ws));
+            c->ws = nullptr;
+            c->ws_bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&c->ws, need));
+        c->ws_bytes = need;
+    }
+    *ic = c->ws;
+    *fin0 = (char *)c->ws + n_q * vec;
+    *fin1 = (char *)c->ws + 2 * n_q * vec;
+    return LT_OK;
+}
+
+extern "C" int lt_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = lt_device_count();
+    int keep = 0;
+    if (n > 0) (void)hipGetDevice(&keep);
+    for (int d = 0; d < n && d < 64; ++d) {
+        Ctx &c = g_ctx[d];
+        if (!c.ws && c.pool.empty() && c.pending.empty()) continue;
+        (void)hipSetDevice(d);
+        (void)hipDeviceSynchronize();
+        if (c.ws) (void)hipFree(c.ws);
+        c.ws = nullptr;
+        c.ws_bytes = 0;
+        for (auto &q : c.pending) for (auto &e : q.e) (void)hipEventDestroy(e);
+        for (auto &q : c.pool) for (auto &e : q.e) (void)hipEventDestroy(e);
+        c.pending.clear();
+        c.pool.clear();
+    }
+    if (n > 0) (void)hipSetDevice(keep);
+    return LT_OK;
+}
+
+extern "C" void lt_default_opts(lt_opts *o)
+{
+    memset(o, 0, sizeof(*o));
+    o->integrator = LT_INTEGRATOR_RK4;
+    o->precision = 32;
+    o->schedule = LT_SCHED_DIRECT;
+    o->row_block = 16;
+    o->n_parts = 1;
+    o->axis_refine_frac = 0.07;
+    o->phi_max = 50.0;
+    o->h_max = 0.0; // 0 -> metric default (0.05 Schwarzschild, 1.0 Kerr)
+}
+
+// ---------------------------------------------------------------------------------------------
+// constant blocks
+// ---------------------------------------------------------------------------------------------
+// _psi_frame, image_lens.py:21-61.
+static void psi_frame(double psi_y, double psi_x, double *d, double *ex, double *ey, bool *in_front)
+{
+    d[0] = sin(psi_x) * cos(psi_y);
+    d[1] = -sin(psi_y);
+    d[2] = cos(psi_x) * cos(psi_y);
+    *in_front = d[2] > 1e-12;
+    auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+    auto norm = [&](const double *a) { return sqrt(dot(a, a)); };
+    const double cx[3] = {1, 0, 0}, cy[3] = {0, 1, 0};
+    double t = dot(cx, d);
+    for (int i = 0; i < 3; ++i) ex[i] = cx[i] - t * d[i];
+    double n = norm(ex);
+    if (n < 1e-12) {
+        t = dot(cy, d);
+        for (int i = 0; i < 3; ++i) ex[i] = cy[i] - t * d[i];
+        n = norm(ex);
+    }
+    n = n > 1e-12 ? n : 1e-12;
+    for (int i = 0; i < 3; ++i) ex[i] /= n;
+    double t1 = dot(cy, d), t2 = dot(cy, ex);
+    for (int i = 0; i < 3; ++i) ey[i] = cy[i] - t1 * d[i] - t2 * ex[i];
+    n = norm(ey);
+    if (n < 1e-12) {
+        ey[0] = d[1] * ex[2] - d[2] * ex[1];
+        ey[1] = d[2] * ex[0] - d[0] * ex[2];
+        ey[2] = d[0] * ex[1] - d[1] * ex[0];
+        n = norm(ey);
+    }
+    n = n > 1e-12 ? n : 1e-12;
+    for (int i = 0; i < 3; ++i) ey[i] /= n;
+}
+
+extern "C" int64_t lt_local_rows(int32_t height, int32_t row_block, int32_t n_parts, int32_t part)
+{
+    if (height <= 0 || row_block <= 0 || n_parts <= 0 || part < 0 || part >= n_parts) return -1;
+    int64_t rows = 0;
+    for (int64_t b = part; b * row_block < height; b += n_parts) {
+        int64_t r0 = b * row_block, r1 = r0 + row_block;
+        rows += (r1 < height ? r1 : height) - r0;
+    }
+    return rows;
+}
+
+extern "C" int64_t lt_global_row(int64_t local_row, int32_t row_block, int32_t n_parts, int32_t part)
+{
+    int64_t b = local_row / row_block, o = local_row - b * row_block;
+    return (b * n_parts + part) * row_block + o;
+}
+
+static int make_metric(const lt_metric *m, double r_obs, double theta_obs, double h_schw, MetricConsts *mc)
+{
+    if (!(m->M > 0.0)) return fail(LT_ERR_INVALID_ARG, "M must be positive");
+    mc->kind = m->kind;
+    mc->M = m->M;
+    mc->a = m->kind == LT_METRIC_KERR ? m->a : 0.0;
+    if (m->kind == LT_METRIC_KERR && fabs(m->a) > m->M)
+        return fail(LT_ERR_INVALID_ARG, "|a|=%g exceeds M=%g", fabs(m->a), m->M); // metrics.py:849-850
+    if (m->kind != LT_METRIC_KERR && m->kind != LT_METRIC_SCHWARZSCHILD)
+        return fail(LT_ERR_INVALID_ARG, "unknown metric kind %d", m->kind);
+    mc->r_obs = r_obs;
+    mc->theta_obs = theta_obs;
+    mc->r_plus = mc->M + sqrt(mc->M * mc->M - mc->a * mc->a); // metrics.py:853
+    mc->r_capture = mc->r_plus * 1.01;                        // metrics.py:428, :579
+    mc->R_S = 2.0 * mc->M;                                    // metrics.py:742
+    mc->phi_h = h_schw;
+    return LT_OK;
+}
+
+template <typename T> static KerrConsts<T> make_kerr(const MetricConsts &mc, double lambda_max, double h_max)
+{
+    KerrConsts<T> k;
+    k.M = (T)mc.M; k.a = (T)mc.a; k.a2 = (T)(mc.a * mc.a); k.two_M = (T)(2.0 * mc.M);
+    k.r_cut = (T)(mc.r_plus * 1.001);
+    k.r_capture = (T)mc.r_capture;
+    k.r_escape = (T)(mc.r_obs * 2.0);
+    k.r_obs = (T)mc.r_obs; k.theta_obs = (T)mc.theta_obs;
+    k.lambda_max = (T)lambda_max;
+    k.h_max = (T)h_max;
+    k.rc4 = (T)(mc.r_capture * 4.0); k.rc2 = (T)(mc.r_capture * 2.0); k.rc12 = (T)(mc.r_capture * 1.2);
+    return k;
+}
+
+template <typename T> static SchwConsts<T> make_schw(const MetricConsts &mc, double phi_max, double h_max)
+{
+    SchwConsts<T> k;
+    k.M = (T)mc.M; k.three_M = (T)(3.0 * mc.M);
+    k.u0 = (T)(1.0 / mc.r_obs);
+    k.u_capture = (T)(1.0 / (mc.R_S * 1.01)); // metrics.py:66
+    k.u_escape = (T)(1.0 / (2.0 * mc.r_obs)); // metrics.py:67
+    k.h_max = (T)h_max; k.phi_max = (T)phi_max;
+    double nf = floor(phi_max / h_max + 1e-9);
+    double rest = phi_max - nf * h_max;
+    if (rest < 1e-9 * h_max) rest = 0.0;
+    k.n_full = (uint32_t)nf;
+    k.h_last = (T)rest;
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage launchers
+// ---------------------------------------------------------------------------------------------
+struct Timer {
+    bool on = false;
+    EventQuad q{};
+    Ctx *ctx = nullptr;
+    int begin(bool enable)
+    {
+        on = enable;
+        if (!on) return LT_OK;
+        int rc = cur_ctx(&ctx);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!ctx->pool.empty()) { q = ctx->pool.back(); ctx->pool.pop_back(); }
+        else for (auto &e : q.e) HIP_TRY(hipEventCreate(&e));
+        return LT_OK;
+    }
+    int mark(int i, hipStream_t s)
+    {
+        if (on) HIP_TRY(hipEventRecord(q.e[i], s));
+        return LT_OK;
+    }
+    void finish()
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> lk(g_mu);
+        ctx->pending.push_back(q);
+    }
+};
+
+extern "C" int lt_timing_collect(double *prologue_ms, double *integrate_ms, double *epilogue_ms, int32_t *calls)
+{
+    Ctx *c;
+    int rc = cur_ctx(&c);
+    if (rc) return rc;
+    double t[3] = {0, 0, 0};
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    for (auto &q : c->pending) {
+        HIP_TRY(hipEventSynchronize(q.e[3]));
+        for (int i = 0; i < 3; ++i) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, q.e[i], q.e[i + 1]));
+            t[i] += ms;
+        }
+        c->pool.push_back(q);
+        ++n;
+    }
+    c->pending.clear();
+    if (prologue_ms) *prologue_ms = t[0];
+    if (integrate_ms) *integrate_ms = t[1];
+    if (epilogue_ms) *epilogue_ms = t[2];
+    if (calls) *calls = n;
+    return LT_OK;
+}
+
+template <typename T>
+static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lambda_max, void *ic, void *fin0,
+                            void *fin1, int64_t n_q, hipStream_t s)
+{
+    using V = typename Vec4<T>::type;
+    unsigned grid = (unsigned)((n_q + 255) / 256);
+    if (mc.kind == LT_METRIC_SCHWARZSCHILD) {
+        SchwConsts<T> k = make_schw<T>(mc, o.phi_max, o.h_max);
+        k_schw_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)ic, (V *)fin0, (V *)fin1, n_q);
+    } else {
+        KerrConsts<T> k = make_kerr<T>(mc, lambda_max, o.h_max);
+        if (o.integrator == LT_INTEGRATOR_RK4) {
+            if (o.schedule == LT_SCHED_DIRECT)
+                k_kerr_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)ic, (V *)fin0, (V *)fin1, n_q);
+            else
+                return fail(LT_ERR_UNSUPPORTED, "queue schedule not built yet");
+        } else {
+            return fail(LT_ERR_UNSUPPORTED, "DP45 integrator not built yet");
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+static int check_opts(const lt_metric *metric, lt_opts *o)
+{
+    if (o->precision != 32 && o->precision != 64) return fail(LT_ERR_INVALID_ARG, "precision must be 32 or 64");
+    if (metric->kind == LT_METRIC_KERR && o->integrator == LT_INTEGRATOR_DP45 && o->precision != 64)
+        return fail(LT_ERR_UNSUPPORTED,
+                    "DP45 at the reference tolerances needs float64 (rtol 1e-8 is below float32 epsilon)");
+    if (o->integrator != LT_INTEGRATOR_DP45 && o->integrator != LT_INTEGRATOR_RK4)
+        return fail(LT_ERR_INVALID_ARG, "unknown integrator %d", o->integrator);
+    if (o->schedule != LT_SCHED_DIRECT && o->schedule != LT_SCHED_QUEUE)
+        return fail(LT_ERR_INVALID_ARG, "unknown schedule %d", o->schedule);
+    if (o->h_max <= 0.0) o->h_max = metric->kind == LT_METRIC_KERR ? 1.0 : 0.05;
+    if (o->phi_max <= 0.0) o->phi_max = 50.0;
+    if (o->row_block <= 0) o->row_block = 16;
+    if (o->n_parts <= 0) o->n_parts = 1;
+    if (o->part < 0 || o->part >= o->n_parts) return fail(LT_ERR_INVALID_ARG, "part %d not in [0, %d)", o->part, o->n_parts);
+    return LT_OK;
+}
+
+extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, const float *d_bg,
+                             int32_t bg_channels, float *d_fa, uint16_t *d_w, int8_t *d_status, uint32_t *d_steps,
+                             float *d_rgb, uint8_t *d_rgba, uint64_t *d_stats)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!cam || !metric || !opts) return fail(LT_ERR_INVALID_ARG, "null camera / metric / opts");
+    if (cam->width <= 0 || cam->height <= 0) return fail(LT_ERR_INVALID_ARG, "empty frame %dx%d", cam->width, cam->height);
+    if (d_bg && bg_channels != 1 && bg_channels != 3) return fail(LT_ERR_INVALID_ARG, "bg_channels must be 1 or 3");
+    lt_opts o = *opts;
+    if ((rc = check_opts(metric, &o))) return rc;
+    MetricConsts mc;
+    if ((rc = make_metric(metric, cam->r_obs, cam->theta_obs, o.h_max, &mc))) return rc;
+
+    CamConsts c;
+    memset(&c, 0, sizeof(c));
+    c.W = cam->width; c.H = cam->height;
+    c.row_block = o.row_block; c.n_parts = o.n_parts; c.part = o.part;
+    c.rows_local = (int)lt_local_rows(c.H, c.row_block, c.n_parts, c.part);
+    c.loop_around = o.loop_around;
+    c.half_W = c.W / 2.0; c.half_H = c.H / 2.0;
+    c.fx = (c.W / 2.0) / tan(cam->hfov / 2); // image_lens.py:138-139
+    c.fy = (c.H / 2.0) / tan(cam->vfov / 2);
+    bool front;
+    psi_frame(cam->psi_y, cam->psi_x, c.d, c.ex, c.ey, &front);
+    c.refine_on = front && metric->kind == LT_METRIC_KERR;
+    if (front) { // image_lens.py:210-214
+        c.bh_x_cam = c.d[0] / c.d[2];
+        double x_lo = fabs((0 - c.half_W) / c.fx - c.bh_x_cam), x_hi = fabs((c.W - 1 - c.half_W) / c.fx - c.bh_x_cam);
+        double m = x_lo > x_hi ? x_lo : x_hi;
+        c.refine_thresh = o.axis_refine_frac * (m > 1e-12 ? m : 1e-12);
+    }
+    // top/bottom symmetry exactly when the reference applies it (image_lens.py:218-220)
+    c.use_tb = o.tb_symmetry && metric->kind == LT_METRIC_KERR &&
+               fabs(cam->theta_obs - M_PI / 2) <= 1e-8 + 1e-5 * (M_PI / 2) && fabs(cam->psi_y) <= 1e-8;
+    if (c.use_tb && o.n_parts != 1) return fail(LT_ERR_UNSUPPORTED, "tb_symmetry needs n_parts == 1");
+    c.trace_rows = c.use_tb ? (c.H + 1) / 2 : c.rows_local;
+    c.tiles_x = (c.W + 7) / 8;
+    if (c.rows_local <= 0) return LT_OK; // a partition may own no rows
+    int tiles_y = (c.trace_rows + 7) / 8;
+    int64_t n_q = (int64_t)c.tiles_x * tiles_y * 64;
+    double lambda_max = fmax(5000.0, 6.0 * cam->r_obs); // metrics.py:1132
+
+    hipStream_t s = (hipStream_t)o.stream;
+    size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
+    void *ic, *fin0, *fin1;
+    if ((rc = get_workspace((size_t)n_q, elem, &ic, &fin0, &fin1))) return rc;
+    Timer tm;
+    if ((rc = tm.begin(o.timing != 0))) return rc;
+    unsigned gq = (unsigned)((n_q + 255) / 256);
+    int64_t n_pix = (int64_t)c.rows_local * c.W;
+    unsigned gp = (unsigned)((n_pix + 255) / 256);
+    FrameOut fo{d_bg, bg_channels, d_fa, d_w, d_status, d_steps, d_rgb, d_rgba, d_stats};
+
+    if ((rc = tm.mark(0, s))) return rc;
+    if (o.precision == 32) k_prologue_camera<float><<<gq, 256, 0, s>>>(c, mc, (float4 *)ic, n_q);
+    else k_prologue_camera<double><<<gq, 256, 0, s>>>(c, mc, (double4 *)ic, n_q);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tm.mark(1, s))) return rc;
+    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, ic, fin0, fin1, n_q, s)
+                           : launch_integrate<double>(mc, o, lambda_max, ic, fin0, fin1, n_q, s);
+    if (rc) return rc;
+    if ((rc = tm.mark(2, s))) return rc;
+    if (o.precision == 32) k_epilogue_frame<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
+    else k_epilogue_frame<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+    HIP_TRY(hipGetLastError());
+    if ((rc = tm.mark(3, s))) return rc;
+    tm.finish();
+    return LT_OK;
+}
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { HIP_TRY(hipMalloc(&p, n ? n : 1)); return LT_OK; }
+};
+
+extern "C" int lt_render(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, const float *bg,
+                         int32_t bg_channels, float *out_fa, uint16_t *out_w, int8_t *out_status, uint32_t *out_steps,
+                         float *out_rgb, uint8_t *out_rgba, lt_stats *stats)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!cam || !metric || !opts) return fail(LT_ERR_INVALID_ARG, "null camera / metric / opts");
+    lt_opts o = *opts;
+    if ((rc = check_opts(metric, &o))) return rc;
+    int64_t rows = lt_local_rows(cam->height, o.row_block, o.n_parts, o.part);
+    if (rows < 0 || cam->width <= 0) return fail(LT_ERR_INVALID_ARG, "bad frame / partition");
+    size_t n = (size_t)rows * cam->width;
+    size_t n_full = (size_t)cam->height * cam->width;
+    int nch = bg ? bg_channels : 3;
+    hipStream_t s = (hipStream_t)o.stream;
+    DevBuf dbg, dfa, dw, dst, dsteps, drgb, drgba, dstats;
+    if (bg) {
+        if ((rc = dbg.alloc(n_full * bg_channels * sizeof(float)))) return rc;
+        HIP_TRY(hipMemcpyAsync(dbg.p, bg, n_full * bg_channels * sizeof(float), hipMemcpyHostToDevice, s));
+    }
+    if (out_fa && (rc = dfa.alloc(n * 4))) return rc;
+    if (out_w && (rc = dw.alloc(n * 2))) return rc;
+    if (out_status && (rc = dst.alloc(n))) return rc;
+    if (out_steps && (rc = dsteps.alloc(n * 4))) return rc;
+    if (out_rgb && (rc = drgb.alloc(n * nch * 4))) return rc;
+    if (out_rgba && (rc = drgba.alloc(n * 4))) return rc;
+    if ((rc = dstats.alloc(LT_STAT_WORDS * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(dstats.p, 0, LT_STAT_WORDS * 8, s));
+    o.timing = 1;
+    double t0, t1, t2; int32_t calls;
+    (void)lt_timing_collect(&t0, &t1, &t2, &calls); // drop stale events
+    rc = lt_render_dev(cam, metric, &o, (const float *)dbg.p, bg_channels, (float *)dfa.p, (uint16_t *)dw.p,
+                       (int8_t *)dst.p, (uint32_t *)dsteps.p, (float *)drgb.p, (uint8_t *)drgba.p, (uint64_t *)dstats.p);
+    if (rc) return rc;
+    if (out_fa) HIP_TRY(hipMemcpyAsync(out_fa, dfa.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (out_w) HIP_TRY(hipMemcpyAsync(out_w, dw.p, n * 2, hipMemcpyDeviceToHost, s));
+    if (out_status) HIP_TRY(hipMemcpyAsync(out_status, dst.p, n, hipMemcpyDeviceToHost, s));
+    if (out_steps) HIP_TRY(hipMemcpyAsync(out_steps, dsteps.p, n * 4, hipMemcpyDeviceToHost, s));
+    if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, drgb.p, n * nch * 4, hipMemcpyDeviceToHost, s));
+    if (out_rgba) HIP_TRY(hipMemcpyAsync(out_rgba, drgba.p, n * 4, hipMemcpyDeviceToHost, s));
+    lt_stats st;
+    memset(&st, 0, sizeof(st));
+    HIP_TRY(hipMemcpyAsync(st.counters, dstats.p, LT_STAT_WORDS * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if ((rc = lt_timing_collect(&st.prologue_ms, &st.integrate_ms, &st.epilogue_ms, &calls))) return rc;
+    if (stats) *stats = st;
+    return LT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// array-in / array-out twins
+// ---------------------------------------------------------------------------------------------
+static int trace_batch(const MetricConsts &mc, lt_opts &o, double lambda_max, const double *alphas, const double *thetas,
+                       const uint8_t *refines, int64_t n, double *out_fa, int64_t *out_w, int8_t *out_status,
+                       uint32_t *out_evals)
+{
+    int rc;
+    if (n < 0) return fail(LT_ERR_INVALID_ARG, "negative ray count");
+    if (n == 0) return LT_OK; // image_lens.py:163-166: empty input is legal
+    if (!alphas || !out_fa || !out_w) return fail(LT_ERR_INVALID_ARG, "null alphas / out_fa / out_w");
+    if (mc.kind == LT_METRIC_KERR && !thetas) return fail(LT_ERR_INVALID_ARG, "Kerr needs thetas");
+    int64_t n_q = (n + 63) / 64 * 64;
+    size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
+    void *ic, *fin0, *fin1;
+    if ((rc = get_workspace((size_t)n_q, elem, &ic, &fin0, &fin1))) return rc;
+    hipStream_t s = nullptr;
+    DevBuf dal, dth, dref, dfa, dw, dst, dev;
+    if ((rc = dal.alloc(n * 8))) return rc;
+    HIP_TRY(hipMemcpyAsync(dal.p, alphas, n * 8, hipMemcpyHostToDevice, s));
+    if (thetas) {
+        if ((rc = dth.alloc(n * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(dth.p, thetas, n * 8, hipMemcpyHostToDevice, s));
+    }
+    if (refines) {
+        if ((rc = dref.alloc(n))) return rc;
+        HIP_TRY(hipMemcpyAsync(dref.p, refines, n, hipMemcpyHostToDevice, s));
+    }
+    if ((rc = dfa.alloc(n * 8)) || (rc = dw.alloc(n * 8))) return rc;
+    if (out_status && (rc = dst.alloc(n))) return rc;
+    if (out_evals && (rc = dev.alloc(n * 4))) return rc;
+    unsigned gq = (unsigned)((n_q + 255) / 256);
+    if (o.precision == 32)
+        k_prologue_arrays<float><<<gq, 256, 0, s>>>(mc, (const double *)dal.p, (const double *)dth.p,
+                                                    (const uint8_t *)dref.p, n, (float4 *)ic, n_q);
+    else
+        k_prologue_arrays<double><<<gq, 256, 0, s>>>(mc, (const double *)dal.p, (const double *)dth.p,
+                                                     (const uint8_t *)dref.p, n, (double4 *)ic, n_q);
+    HIP_TRY(hipGetLastError());
+    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, ic, fin0, fin1, n_q, s)
+                           : launch_integrate<double>(mc, o, lambda_max, ic, fin0, fin1, n_q, s);
+    if (rc) return rc;
+    unsigned gn = (unsigned)((n + 255) / 256);
+    if (o.precision == 32)
+        k_epilogue_arrays<float><<<gn, 256, 0, s>>>(mc, (const float4 *)fin0, (const float4 *)fin1, n, (double *)dfa.p,
+                                                    (int64_t *)dw.p, (int8_t *)dst.p, (uint32_t *)dev.p);
+    else
+        k_epilogue_arrays<double><<<gn, 256, 0, s>>>(mc, (const double4 *)fin0, (const double4 *)fin1, n, (double *)dfa.p,
+                                                     (int64_t *)dw.p, (int8_t *)dst.p, (uint32_t *)dev.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_fa, dfa.p, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_w, dw.p, n * 8, hipMemcpyDeviceToHost, s));
+    if (out_status) HIP_TRY(hipMemcpyAsync(out_status, dst.p, n, hipMemcpyDeviceToHost, s));
+    if (out_evals) HIP_TRY(hipMemcpyAsync(out_evals, dev.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return LT_OK;
+}
+
+extern "C" int lt_trace_batch_schw(double M, double r_obs, const double *alphas, int64_t n, double phi_max, double h_max,
+                                   int precision, double *out_fa, int64_t *out_w, int8_t *out_status, uint32_t *out_rhs_evals)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    lt_metric m{LT_METRIC_SCHWARZSCHILD, 0, M, 0.0};
+    lt_opts o;
+    lt_default_opts(&o);
+    o.precision = precision; o.phi_max = phi_max; o.h_max = h_max;
+    if ((rc = check_opts(&m, &o))) return rc;
+    MetricConsts mc;
+    if ((rc = make_metric(&m, r_obs, M_PI / 2, o.h_max, &mc))) return rc;
+    return trace_batch(mc, o, 0.0, alphas, nullptr, nullptr, n, out_fa, out_w, out_status, out_rhs_evals);
+}
+
+extern "C" int lt_trace_batch_kerr(double M, double a, double r_obs, const double *alphas, const double *thetas,
+                                   double theta_obs, double lambda_max, const uint8_t *axis_refines, int integrator,
+                                   int precision, int schedule, int64_t n, double *out_fa, int64_t *out_w,
+                                   int8_t *out_status, uint32_t *out_rhs_evals)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    lt_metric m{LT_METRIC_KERR, 0, M, a};
+    lt_opts o;
+    lt_default_opts(&o);
+    o.integrator = integrator; o.precision = precision; o.schedule = schedule;
+    if ((rc = check_opts(&m, &o))) return rc;
+    MetricConsts mc;
+    if ((rc = make_metric(&m, r_obs, theta_obs, 0.0, &mc))) return rc;
+    return trace_batch(mc, o, lambda_max, alphas, thetas, axis_refines, n, out_fa, out_w, out_status, out_rhs_evals);
+}
+
+extern "C" int lt_kerr_rhs_probe(double M, double a, const double *states, const double *p_phi, int64_t n, int precision,
+                                 double *out)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (n <= 0) return LT_OK;
+    lt_metric m{LT_METRIC_KERR, 0, M, a};
+    MetricConsts mc;
+    if ((rc = make_metric(&m, 50.0, M_PI / 2, 0.0, &mc))) return rc;
+    DevBuf ds, dp, dout;
+    if ((rc = ds.alloc(n * 40)) || (rc = dp.alloc(n * 8)) || (rc = dout.alloc(n * 40))) return rc;
+    HIP_TRY(hipMemcpy(ds.p, states, n * 40, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dp.p, p_phi, n * 8, hipMemcpyHostToDevice));
+    unsigned g = (unsigned)((n + 63) / 64);
+    if (precision == 32)
+        k_kerr_rhs_probe<float><<<g, 64>>>(make_kerr<float>(mc, 5000.0, 1.0), (const double *)ds.p, (const double *)dp.p, n,
+                                           (double *)dout.p);
+    else
+        k_kerr_rhs_probe<double><<<g, 64>>>(make_kerr<double>(mc, 5000.0, 1.0), (const double *)ds.p, (const double *)dp.p,
+                                            n, (double *)dout.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, n * 40, hipMemcpyDeviceToHost));
+    return LT_OK;
+}
+
+extern "C" int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t height, int32_t width, int32_t elem_bytes,
+                                   int32_t row_block, int32_t n_parts, int32_t part, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    int64_t rows = lt_local_rows(height, row_block, n_parts, part);
+    if (rows < 0 || width <= 0 || elem_bytes <= 0) return fail(LT_ERR_INVALID_ARG, "bad scatter arguments");
+    if (rows == 0) return LT_OK;
+    int64_t row_bytes = (int64_t)width * elem_bytes;
+    dim3 grid((unsigned)((row_bytes + 16 * 256 - 1) / (16 * 256)), (unsigned)rows);
+    k_scatter_rows<<<grid, 256, 0, (hipStream_t)stream>>>((const uint8_t *)d_part, (uint8_t *)d_full, (int)rows, row_bytes,
+                                                          row_block, n_parts, part);
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+extern "C" int lt_valu_peak_probe(int mode, int iters, double *tflops)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    DevBuf sink;
+    if ((rc = sink.alloc(64))) return rc;
+    hipDeviceProp_t prop;
+    int dev;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    unsigned grid = (unsigned)prop.multiProcessorCount * 8; // 8 blocks of 256 = 32 waves per CU
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    k_valu_probe<<<grid, 256>>>(mode, 16, (float *)sink.p); // warm-up
+    HIP_TRY(hipEventRecord(e0, 0));
+    k_valu_probe<<<grid, 256>>>(mode, iters, (float *)sink.p);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    double fma_per_lane = (double)iters * 64.0 * (mode == 1 ? 2.0 : 1.0);
+    double flops = fma_per_lane * 2.0 * 256.0 * grid;
+    if (tflops) *tflops = flops / (ms * 1e-3) / 1e12;
+    return LT_OK;
+}

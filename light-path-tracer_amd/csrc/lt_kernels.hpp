@@ -1,0 +1,549 @@
+// lt_kernels.hpp -- __global__ kernels of the three-stage ray pipeline.
+//
+//   K1 prologue  (float64, convergent)  pixel -> (alpha, theta) -> initial momenta      16 B/ray out
+//   K2 integrate (float32 or float64)   the hot loop, registers only                    16 B in, 32 B out
+//   K3 epilogue  (float64, convergent)  exit angle, winding, colouring, coalesced stores
+//
+// Why three kernels and not one: K2 is >95 % of the time and pure VALU; keeping the float64
+// trigonometry of the camera model and of the colouring out of it keeps its register
+// allocation at the size of the integrator alone, and lets the epilogue write whole rows
+// coalesced whatever order the integrate kernel finished the rays in.  The intermediate
+// records cost 64 B/ray of HBM traffic against >= 5e4 VALU instructions per ray.
+//
+// Ray order ("tile order"): ray q = tile * 64 + lane, tile = ty * tiles_x + tx, lane = ly * 8 + lx
+// for pixel (tx*8 + lx, ty*8 + ly) of the partition's local rows, so the 64 lanes of a wavefront
+// integrate an 8x8 pixel tile: neighbouring rays take nearly the same number of steps.
+#pragma once
+#include "lt_device.hpp"
+
+namespace lt {
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+constexpr int FLAG_OK = 1, FLAG_REFINE = 2, FLAG_PAD = 4;
+
+// Wave-uniform description of the camera and of the row partition (all float64).
+struct CamConsts {
+    int W, H;            // full frame
+    int rows_local;      // rows this partition owns
+    int trace_rows;      // rows actually traced (tb_symmetry: (H+1)/2), n_parts == 1 only
+    int use_tb;          // 1: rows >= H - H/2 copy row H-1-j (reference quirk Q1)
+    int tiles_x;
+    int row_block, n_parts, part;
+    int loop_around;
+    double half_W, half_H, fx, fy; // x_cam = (ix - W/2) / fx  (image_lens.py:141-142)
+    double d[3], ex[3], ey[3];     // _psi_frame, image_lens.py:38-61
+    int refine_on;                 // BH in front of the camera (image_lens.py:211)
+    double bh_x_cam, refine_thresh; // |x_cam - bh_x| <= thresh (image_lens.py:212-214)
+};
+
+struct MetricConsts { // float64 view of the metric for K1 / K3
+    int kind;
+    double M, a, r_obs, theta_obs, r_plus, r_capture, R_S;
+    double phi_h; // Schwarzschild step h_max (to rebuild phi_f)
+};
+
+__device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
+{
+    int b = lrow / c.row_block, o = lrow - b * c.row_block;
+    return (b * c.n_parts + c.part) * c.row_block + o;
+}
+
+__device__ __forceinline__ void q_to_pixel(const CamConsts &c, int64_t q, int &ix, int &lrow)
+{
+    int lane = (int)(q & 63);
+    int64_t tile = q >> 6;
+    int ty = (int)(tile / c.tiles_x), tx = (int)(tile - (int64_t)ty * c.tiles_x);
+    ix = tx * 8 + (lane & 7);
+    lrow = ty * 8 + (lane >> 3);
+}
+
+__device__ __forceinline__ int64_t pixel_to_q(const CamConsts &c, int ix, int lrow)
+{
+    int64_t tile = (int64_t)(lrow >> 3) * c.tiles_x + (ix >> 3);
+    return (tile << 6) | ((lrow & 7) << 3) | (ix & 7);
+}
+
+// (alpha, theta) of a pixel: image_lens.py:141-152 (alpha, rounded to float32 -- quirk Q2) and
+// image_lens.py:197-208 (theta).
+__device__ __forceinline__ void pixel_angles(const CamConsts &c, int ix, int grow, double &alpha, double &theta)
+{
+    double x_cam = ((double)ix - c.half_W) / c.fx;
+    double y_cam = ((double)grow - c.half_H) / c.fy;
+    double denom = sqrt(1.0 + x_cam * x_cam + y_cam * y_cam);
+    double cos_alpha = ((x_cam * c.d[0]) + (y_cam * c.d[1]) + c.d[2]) / denom;
+    cos_alpha = fmin(fmax(cos_alpha, -1.0), 1.0);
+    alpha = (double)(float)acos(cos_alpha);
+    double vx = x_cam / denom, vy = y_cam / denom, vz = 1.0 / denom;
+    theta = atan2(vx * c.ex[0] + vy * c.ex[1] + vz * c.ex[2], vx * c.ey[0] + vy * c.ey[1] + vz * c.ey[2]);
+}
+
+// Kerr initial momenta, metrics.py:148-218, float64, operation order as written there.
+__device__ __forceinline__ bool kerr_initial_momenta(const MetricConsts &m, double alpha, double theta,
+                                                     double &p_r, double &p_theta, double &p_phi)
+{
+    double r = m.r_obs, a = m.a, M_ = m.M;
+    double sin_th = sin(m.theta_obs), cos_th = cos(m.theta_obs);
+    double sin_th_sq = sin_th * sin_th;
+    if (sin_th_sq < 1e-15) sin_th_sq = 1e-15;
+    double Sigma = r * r + a * a * cos_th * cos_th;
+    double Delta = r * r - 2.0 * M_ * r + a * a;
+    p_r = p_theta = p_phi = 0.0;
+    if (Delta <= 0.0 || Sigma <= 0.0) return false;
+    double sin_alpha = sin(alpha), sin_screen, cos_screen;
+    sincos(theta, &sin_screen, &cos_screen);
+    double rho = r * sin_alpha * sqrt(Sigma) / sqrt(Delta);
+    double alpha_screen = -rho * sin_screen, beta_screen = -rho * cos_screen;
+    double xi = -alpha_screen * sin_th;
+    double eta = beta_screen * beta_screen + cos_th * cos_th * (alpha_screen * alpha_screen - a * a);
+    double L = xi, Q = eta;
+    double Theta = Q - cos_th * cos_th * (L * L / sin_th_sq - a * a);
+    if (Theta < 0.0) Theta = 0.0;
+    p_theta = (cos_screen > 0.0 ? -1.0 : 1.0) * sqrt(Theta);
+    double A_val = (r * r + a * a) * (r * r + a * a) - a * a * Delta * sin_th_sq;
+    double g_tt = -A_val / (Sigma * Delta);
+    double g_tphi = -2.0 * M_ * a * r / (Sigma * Delta);
+    double g_rr = Delta / Sigma;
+    double g_thth = 1.0 / Sigma;
+    double g_phiphi = (Delta - a * a * sin_th_sq) / (Sigma * Delta * sin_th_sq);
+    double other = g_tt + 2.0 * g_tphi * (-1.0) * L + g_thth * p_theta * p_theta + g_phiphi * L * L;
+    double p_r_sq = -other / g_rr;
+    if (p_r_sq < 0.0) p_r_sq = 0.0;
+    p_r = -sqrt(p_r_sq);
+    p_phi = L;
+    return true;
+}
+
+// Schwarzschild initial w = du/dphi, metrics.py:51-63.
+__device__ __forceinline__ bool schw_initial_w(const MetricConsts &m, double alpha, double &w0)
+{
+    w0 = 0.0;
+    double f0 = 1.0 - m.R_S / m.r_obs;
+    if (f0 <= 0.0) return false;
+    double b = m.r_obs * sin(alpha) / sqrt(f0);
+    if (b == 0.0) return false;
+    double u = 1.0 / m.r_obs;
+    double w0_sq = 1.0 / (b * b) - u * u + 2.0 * m.M * u * u * u;
+    if (w0_sq < 0.0) return false;
+    w0 = sqrt(w0_sq);
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_ic(typename Vec4<T>::type *ic, int64_t q, double a, double b, double c, int flags)
+{
+    typename Vec4<T>::type v;
+    v.x = (T)a; v.y = (T)b; v.z = (T)c; v.w = (T)flags;
+    ic[q] = v;
+}
+
+// ---- K1: camera prologue -------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_prologue_camera(CamConsts c, MetricConsts m,
+                                                         typename Vec4<T>::type *__restrict__ ic, int64_t n_q)
+{
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_q) return;
+    int ix, lrow;
+    q_to_pixel(c, q, ix, lrow);
+    if (ix >= c.W || lrow >= c.trace_rows) { store_ic<T>(ic, q, 0, 0, 0, FLAG_PAD); return; }
+    int grow = local_to_global_row(c, lrow);
+    double alpha, theta;
+    pixel_angles(c, ix, grow, alpha, theta);
+    int flags = 0;
+    if (c.refine_on) {
+        double x_cam = ((double)ix - c.half_W) / c.fx;
+        if (fabs(x_cam - c.bh_x_cam) <= c.refine_thresh) flags |= FLAG_REFINE;
+    }
+    if (m.kind == 0) {
+        double w0;
+        if (schw_initial_w(m, alpha, w0)) flags |= FLAG_OK;
+        store_ic<T>(ic, q, w0, 0, 0, flags);
+    } else {
+        double p_r, p_th, p_phi;
+        if (kerr_initial_momenta(m, alpha, theta, p_r, p_th, p_phi)) flags |= FLAG_OK;
+        store_ic<T>(ic, q, p_r, p_th, p_phi, flags);
+    }
+}
+
+// ---- K1': prologue for caller-supplied (alpha, theta, refine) arrays (batch twins) ---------
+template <typename T>
+__global__ void __launch_bounds__(256) k_prologue_arrays(MetricConsts m, const double *__restrict__ alphas,
+                                                         const double *__restrict__ thetas,
+                                                         const uint8_t *__restrict__ refines, int64_t n,
+                                                         typename Vec4<T>::type *__restrict__ ic, int64_t n_q)
+{
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_q) return;
+    if (q >= n) { store_ic<T>(ic, q, 0, 0, 0, FLAG_PAD); return; }
+    int flags = (refines && refines[q]) ? FLAG_REFINE : 0;
+    if (m.kind == 0) {
+        double w0;
+        if (schw_initial_w(m, alphas[q], w0)) flags |= FLAG_OK;
+        store_ic<T>(ic, q, w0, 0, 0, flags);
+    } else {
+        double p_r, p_th, p_phi;
+        if (kerr_initial_momenta(m, alphas[q], thetas[q], p_r, p_th, p_phi)) flags |= FLAG_OK;
+        store_ic<T>(ic, q, p_r, p_th, p_phi, flags);
+    }
+}
+
+// ---- K2: integrate --------------------------------------------------------------------------
+// Final record: fin0 = (r, theta, phi, p_r), fin1 = (p_theta, p_phi, event, steps)   [Kerr]
+//               fin0 = (u, w, phi_last, full_steps), fin1 = (0, 0, event, steps)      [Schwarzschild]
+template <typename T>
+__device__ __forceinline__ void store_fin(typename Vec4<T>::type *fin0, typename Vec4<T>::type *fin1, int64_t q,
+                                          T a, T b, T c, T d, T e, T f, int ev, uint32_t steps)
+{
+    typename Vec4<T>::type v0, v1;
+    v0.x = a; v0.y = b; v0.z = c; v0.w = d;
+    v1.x = e; v1.y = f; v1.z = (T)ev; v1.w = (T)steps;
+    fin0[q] = v0;
+    fin1[q] = v1;
+}
+
+// Direct schedule: one work-item per ray, a wavefront = one 8x8 tile.
+template <typename T>
+__global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k, const typename Vec4<T>::type *__restrict__ ic,
+                                                         typename Vec4<T>::type *__restrict__ fin0,
+                                                         typename Vec4<T>::type *__restrict__ fin1, int64_t n_q)
+{
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_q) return;
+    typename Vec4<T>::type rec = ic[q];
+    int flags = (int)rec.w;
+    State5<T> y;
+    y.r = k.r_obs; y.th = k.theta_obs; y.ph = T(0); y.pr = rec.x; y.pth = rec.y;
+    int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
+    uint32_t steps = 0;
+    if (flags & FLAG_OK) {
+        RayConsts<T> rc = make_ray_consts(k, rec.z);
+        ev = kerr_rk4_trace(k, rc, y, (flags & FLAG_REFINE) != 0, steps);
+    }
+    store_fin<T>(fin0, fin1, q, y.r, y.th, y.ph, y.pr, y.pth, rec.z, ev, steps);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_schw_rk4_direct(SchwConsts<T> k, const typename Vec4<T>::type *__restrict__ ic,
+                                                         typename Vec4<T>::type *__restrict__ fin0,
+                                                         typename Vec4<T>::type *__restrict__ fin1, int64_t n_q)
+{
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_q) return;
+    typename Vec4<T>::type rec = ic[q];
+    int flags = (int)rec.w;
+    T u = k.u0, w = rec.x, phi_last = T(0);
+    int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
+    uint32_t steps = 0;
+    if (flags & FLAG_OK) ev = schw_trace(k, u, w, steps, phi_last);
+    uint32_t total = steps + ((ev == EV_CAPTURED || ev == EV_ESCAPED) ? 1u : 0u);
+    store_fin<T>(fin0, fin1, q, u, w, phi_last, (T)steps, T(0), T(0), ev, total);
+}
+
+// ---- K3: epilogue -----------------------------------------------------------------------------
+// int(abs(phi) // pi) with Python's float floor-division (metrics.py:133, :372).
+__device__ __forceinline__ long long half_orbits(double phi)
+{
+    const double PI = 3.141592653589793;
+    double a = fabs(phi);
+    double mod = fmod(a, PI);
+    double div = (a - mod) / PI;
+    double fl = 0.0;
+    if (div != 0.0) {
+        fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+    }
+    return (long long)fl;
+}
+
+struct RayResult {
+    int status;       // LT_STATUS_*
+    double fa;        // final_alpha (NaN unless escaped)
+    long long n_half;
+    uint32_t steps, evals;
+};
+
+// _kerr_extract_angle, metrics.py:363-416 (float64, as written).
+__device__ __forceinline__ void kerr_extract(const MetricConsts &m, double r_f, double th_f, double phi_f,
+                                             double p_r_f, double p_th_f, double p_phi, int ev, RayResult &o)
+{
+    const double NaN = __builtin_nan("");
+    o.fa = NaN;
+    if (ev == EV_INVALID) { o.status = 0; o.n_half = 0; return; }
+    o.n_half = half_orbits(phi_f);
+    if (r_f <= m.r_capture * 1.1 || ev == EV_CAPTURED) { o.status = -1; return; }
+    if (!isfinite(r_f) || !isfinite(th_f) || !isfinite(phi_f)) { o.status = 0; o.n_half = 0; return; }
+    double a = m.a, M_ = m.M, p_t = -1.0;
+    double sin_th, cos_th;
+    sincos(th_f, &sin_th, &cos_th);
+    double sin_th_sq = sin_th * sin_th;
+    if (sin_th_sq < 1e-15) sin_th_sq = 1e-15;
+    double Sigma_f = r_f * r_f + a * a * cos_th * cos_th;
+    double Delta_f = r_f * r_f - 2.0 * M_ * r_f + a * a;
+    if (Sigma_f <= 1e-15 || fabs(Delta_f) <= 1e-15) { o.status = 0; return; }
+    double dr_dl = Delta_f / Sigma_f * p_r_f;
+    double dth_dl = p_th_f / Sigma_f;
+    double dphi_dl = (-2.0 * M_ * a * r_f / (Sigma_f * Delta_f) * p_t
+                      + (Delta_f - a * a * sin_th_sq) / (Sigma_f * Delta_f * sin_th_sq) * p_phi);
+    double sin_phi, cos_phi;
+    sincos(phi_f, &sin_phi, &cos_phi);
+    double vx = sin_th * cos_phi * dr_dl + r_f * cos_th * cos_phi * dth_dl - r_f * sin_th * sin_phi * dphi_dl;
+    double vy = sin_th * sin_phi * dr_dl + r_f * cos_th * sin_phi * dth_dl + r_f * sin_th * cos_phi * dphi_dl;
+    double vz = cos_th * dr_dl - r_f * sin_th * dth_dl;
+    if (!isfinite(vx) || !isfinite(vy) || !isfinite(vz)) { o.status = 0; return; }
+    double v_mag = sqrt(vx * vx + vy * vy + vz * vz);
+    o.status = 1;
+    if (v_mag < 1e-30) return;
+    o.fa = acos(fmin(fmax(-vx / v_mag, -1.0), 1.0));
+}
+
+// _schwarzschild_trace_ray_numba tail, metrics.py:129-145.
+__device__ __forceinline__ void schw_extract(const MetricConsts &m, double u_f, double w_f, double phi_f, int ev,
+                                             RayResult &o)
+{
+    const double NaN = __builtin_nan("");
+    o.fa = NaN;
+    if (ev == EV_INVALID) { o.status = 0; o.n_half = 0; return; }
+    double r_f = 1.0 / u_f;
+    o.n_half = half_orbits(phi_f);
+    if (ev == EV_CAPTURED || r_f <= m.R_S * 1.1) { o.status = -1; return; }
+    double dr_dphi = -w_f / (u_f * u_f);
+    double sin_phi, cos_phi;
+    sincos(phi_f, &sin_phi, &cos_phi);
+    double heading = atan2(dr_dphi * sin_phi + r_f * cos_phi, dr_dphi * cos_phi - r_f * sin_phi);
+    o.status = 1;
+    o.fa = acos(fmin(fmax(-cos(heading), -1.0), 1.0));
+}
+
+template <typename T>
+__device__ __forceinline__ void load_result(const MetricConsts &m, const typename Vec4<T>::type *fin0,
+                                            const typename Vec4<T>::type *fin1, int64_t q, RayResult &o)
+{
+    typename Vec4<T>::type v0 = fin0[q], v1 = fin1[q];
+    int ev = (int)v1.z;
+    o.steps = (uint32_t)v1.w;
+    if (m.kind == 0) {
+        double phi_f = (double)v0.w * m.phi_h + (double)v0.z;
+        schw_extract(m, (double)v0.x, (double)v0.y, phi_f, ev, o);
+    } else {
+        kerr_extract(m, (double)v0.x, (double)v0.y, (double)v0.z, (double)v0.w, (double)v1.x, (double)v1.y, ev, o);
+    }
+    o.evals = o.steps * 4u;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void accumulate_stats(uint64_t *stats, bool counted, const RayResult &o)
+{
+    if (!stats) return;
+    unsigned long long rays = wave_sum(counted ? 1ull : 0ull);
+    unsigned long long steps = wave_sum(counted ? (unsigned long long)o.steps : 0ull);
+    unsigned long long evals = wave_sum(counted ? (unsigned long long)o.evals : 0ull);
+    unsigned long long esc = wave_sum(counted && o.status == 1 ? 1ull : 0ull);
+    unsigned long long cap = wave_sum(counted && o.status == -1 ? 1ull : 0ull);
+    unsigned long long inv = wave_sum(counted && o.status == 0 ? 1ull : 0ull);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)&stats[0], rays);
+        atomicAdd((unsigned long long *)&stats[1], steps);
+        atomicAdd((unsigned long long *)&stats[2], evals);
+        atomicAdd((unsigned long long *)&stats[3], esc);
+        atomicAdd((unsigned long long *)&stats[4], cap);
+        atomicAdd((unsigned long long *)&stats[5], inv);
+    }
+}
+
+struct FrameOut {
+    const float *bg; int bg_c;
+    float *fa; uint16_t *w; int8_t *status; uint32_t *steps; float *rgb; uint8_t *rgba;
+    uint64_t *stats;
+};
+
+// Colour of one pixel, render_lensed_image (image_lens.py:296-397); rgb[3] float32.
+__device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int ix, int grow, float fa32,
+                                      int winding, float *rgb, int &nch)
+{
+    nch = o.bg ? o.bg_c : 3;
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    if (!isfinite(fa32)) return;
+    const float half_pi_f = 1.57079637050628662109375f; // float32(pi/2): NEP-50 weak-scalar compare
+    if (fa32 > half_pi_f) {
+        const float wc[5][3] = {{0.0f, 0.2f, 1.0f}, {0.0f, 0.7f, 1.0f}, {0.0f, 1.0f, 0.4f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.4f, 0.0f}};
+        int idx = winding > 4 ? 4 : winding;
+        if (nch == 1) rgb[0] = wc[idx][0] * 0.299f + wc[idx][1] * 0.587f + wc[idx][2] * 0.114f;
+        else { rgb[0] = wc[idx][0]; rgb[1] = wc[idx][1]; rgb[2] = wc[idx][2]; }
+        return;
+    }
+    if (!o.bg) { rgb[0] = rgb[1] = rgb[2] = 1.0f; return; } // shadow mode: escaped = white
+    double x_cam = ((double)ix - c.half_W) / c.fx;
+    double y_cam = ((double)grow - c.half_H) / c.fy;
+    double denom = sqrt(1.0 + x_cam * x_cam + y_cam * y_cam);
+    double vx = x_cam / denom, vy = y_cam / denom, vz = 1.0 / denom;
+    double th = atan2(vx * c.ex[0] + vy * c.ex[1] + vz * c.ex[2], vx * c.ey[0] + vy * c.ey[1] + vz * c.ey[2]);
+    double sin_fa, cos_fa, sin_th, cos_th;
+    sincos((double)fa32, &sin_fa, &cos_fa);
+    sincos(th, &sin_th, &cos_th);
+    double svx = cos_fa * c.d[0] + sin_fa * (sin_th * c.ex[0] + cos_th * c.ey[0]);
+    double svy = cos_fa * c.d[1] + sin_fa * (sin_th * c.ex[1] + cos_th * c.ey[1]);
+    double svz = cos_fa * c.d[2] + sin_fa * (sin_th * c.ex[2] + cos_th * c.ey[2]);
+    bool front = svz > 1e-12;
+    long long sx = -1, sy = -1;
+    if (c.loop_around) {
+        double sxc = front ? svx / svz : 0.0, syc = front ? svy / svz : 0.0;
+        sx = (long long)rint(sxc * c.fx + c.half_W);
+        sy = (long long)rint(syc * c.fy + c.half_H);
+        sx %= c.W; if (sx < 0) sx += c.W;
+        sy %= c.H; if (sy < 0) sy += c.H;
+        front = true;
+    } else if (front) {
+        sx = (long long)rint(svx / svz * c.fx + c.half_W);
+        sy = (long long)rint(svy / svz * c.fy + c.half_H);
+    }
+    if (front && sy >= 0 && sy < c.H && sx >= 0 && sx < c.W) {
+        const float *p = o.bg + ((size_t)sy * c.W + sx) * nch;
+        rgb[0] = p[0];
+        if (nch == 3) { rgb[1] = p[1]; rgb[2] = p[2]; }
+    } else { // magenta, image_lens.py:381-388
+        rgb[0] = 1.0f;
+        if (nch == 3) { rgb[1] = 0.0f; rgb[2] = 1.0f; }
+    }
+}
+
+// One thread per local pixel, row-major: every output array is written fully coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256) k_epilogue_frame(CamConsts c, MetricConsts m,
+                                                        const typename Vec4<T>::type *__restrict__ fin0,
+                                                        const typename Vec4<T>::type *__restrict__ fin1, FrameOut o)
+{
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t n_pix = (int64_t)c.rows_local * c.W;
+    bool live = p < n_pix;
+    RayResult res;
+    res.status = 0; res.fa = 0; res.n_half = 0; res.steps = 0; res.evals = 0;
+    bool counted = false;
+    if (live) {
+        int lrow = (int)(p / c.W), ix = (int)(p - (int64_t)lrow * c.W);
+        int src_row = lrow;
+        if (c.use_tb && lrow >= c.H - c.H / 2) src_row = c.H - 1 - lrow; // quirk Q1 (image_lens.py:272-276)
+        counted = (src_row == lrow);
+        load_result<T>(m, fin0, fin1, pixel_to_q(c, ix, src_row), res);
+        float fa32 = (res.status == 1) ? (float)res.fa : __builtin_nanf("");
+        long long wl = res.n_half < 0 ? 0 : (res.n_half > 65535 ? 65535 : res.n_half);
+        if (o.fa) o.fa[p] = fa32;
+        if (o.w) o.w[p] = (uint16_t)wl;
+        if (o.status) o.status[p] = (int8_t)res.status;
+        if (o.steps) o.steps[p] = res.steps;
+        if (o.rgb || o.rgba) {
+            float rgb[3]; int nch;
+            int grow = local_to_global_row(c, lrow);
+            shade(c, o, ix, grow, fa32, (int)wl, rgb, nch);
+            if (o.rgb) for (int ch = 0; ch < nch; ++ch) o.rgb[p * nch + ch] = rgb[ch];
+            if (o.rgba) { // matplotlib imsave: (x * 255).astype(uint8) in float32, alpha 255
+                uchar4 px;
+                px.x = (uint8_t)(rgb[0] * 255.0f);
+                px.y = (uint8_t)(rgb[nch == 1 ? 0 : 1] * 255.0f);
+                px.z = (uint8_t)(rgb[nch == 1 ? 0 : 2] * 255.0f);
+                px.w = 255;
+                reinterpret_cast<uchar4 *>(o.rgba)[p] = px;
+            }
+        }
+    }
+    accumulate_stats(o.stats, counted, res);
+}
+
+// Epilogue of the batch twins: float64 final_alpha, int64 winding (metrics.py:667-668, :678-679).
+template <typename T>
+__global__ void __launch_bounds__(256) k_epilogue_arrays(MetricConsts m, const typename Vec4<T>::type *__restrict__ fin0,
+                                                         const typename Vec4<T>::type *__restrict__ fin1, int64_t n,
+                                                         double *__restrict__ out_fa, int64_t *__restrict__ out_w,
+                                                         int8_t *__restrict__ out_status, uint32_t *__restrict__ out_evals)
+{
+    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    RayResult res;
+    load_result<T>(m, fin0, fin1, q, res);
+    out_fa[q] = (res.status == 1) ? res.fa : __builtin_nan("");
+    out_w[q] = res.n_half;
+    if (out_status) out_status[q] = (int8_t)res.status;
+    if (out_evals) out_evals[q] = res.evals;
+}
+
+// ---- misc -----------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_kerr_rhs_probe(KerrConsts<T> k, const double *__restrict__ states, const double *__restrict__ p_phi,
+                                 int64_t n, double *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RayConsts<T> rc = make_ray_consts(k, (T)p_phi[i]);
+    T dr, dth, dph, dpr, dpth;
+    kerr_rhs<T>(k, rc, (T)states[i * 5 + 0], (T)states[i * 5 + 1], (T)states[i * 5 + 3], (T)states[i * 5 + 4],
+                dr, dth, dph, dpr, dpth);
+    out[i * 5 + 0] = dr; out[i * 5 + 1] = dth; out[i * 5 + 2] = dph; out[i * 5 + 3] = dpr; out[i * 5 + 4] = dpth;
+}
+
+// Row scatter after the multi-GPU gather: partition rows -> full frame, 16 B per lane where possible.
+__global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__restrict__ full, int rows_local,
+                               int64_t row_bytes, int row_block, int n_parts, int part_id)
+{
+    int lrow = blockIdx.y;
+    if (lrow >= rows_local) return;
+    int b = lrow / row_block, o = lrow - b * row_block;
+    int64_t grow = (int64_t)(b * n_parts + part_id) * row_block + o;
+    const uint8_t *src = part + (int64_t)lrow * row_bytes;
+    uint8_t *dst = full + grow * row_bytes;
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i + 16 <= row_bytes && (row_bytes & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    } else {
+        for (int64_t j = i; j < i + 16 && j < row_bytes; ++j) dst[j] = src[j];
+    }
+}
+
+// FP32 VALU issue-rate probe: 8 independent FMA chains per lane.
+__global__ void __launch_bounds__(256) k_valu_probe(int mode, int iters, float *sink)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    float x = threadIdx.x * 1e-3f + 1.0f;
+    if (mode == 0) {
+        float a0 = x, a1 = x + 1, a2 = x + 2, a3 = x + 3, a4 = x + 4, a5 = x + 5, a6 = x + 6, a7 = x + 7;
+        const float m = 0.999f, b = 1e-3f;
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\t"
+                             "v_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"
+                             "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\t"
+                             "v_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                             : "v"(m), "v"(b));
+            }
+        }
+        float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+        if (s == 12345.678f) sink[0] = s;
+    } else {
+        v2f a0 = {x, x + 1}, a1 = {x + 2, x + 3}, a2 = {x + 4, x + 5}, a3 = {x + 6, x + 7};
+        v2f a4 = {x + 8, x + 9}, a5 = {x + 10, x + 11}, a6 = {x + 12, x + 13}, a7 = {x + 14, x + 15};
+        const v2f m = {0.999f, 0.998f}, b = {1e-3f, 2e-3f};
+        for (int i = 0; i < iters; ++i) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n\tv_pk_fma_f32 %1, %1, %8, %9\n\t"
+                             "v_pk_fma_f32 %2, %2, %8, %9\n\tv_pk_fma_f32 %3, %3, %8, %9\n\t"
+                             "v_pk_fma_f32 %4, %4, %8, %9\n\tv_pk_fma_f32 %5, %5, %8, %9\n\t"
+                             "v_pk_fma_f32 %6, %6, %8, %9\n\tv_pk_fma_f32 %7, %7, %8, %9"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                             : "v"(m), "v"(b));
+            }
+        }
+        v2f s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+        if (s.x + s.y == 12345.678f) sink[0] = s.x;
+    }
+}
+
+} // namespace lt

@@ -1,0 +1,275 @@
+"""ctypes binding of libltrace_hip.so (C-ABI: include/ltrace.h).
+
+Thin by design: structs, argument marshalling and error translation only.  The
+library is the product; it is HIP-only.  If the shared object is missing, or no
+GPU is visible, calls raise -- there is no CPU fallback here or anywhere in this
+package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("LTRACE_LIB", os.path.join(_HERE, "lib", "libltrace_hip.so"))
+
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+METRIC_SCHWARZSCHILD, METRIC_KERR = 0, 1
+INTEGRATOR_DP45, INTEGRATOR_RK4 = 0, 1
+SCHED_DIRECT, SCHED_QUEUE = 0, 1
+STAT_RAYS, STAT_STEPS, STAT_RHS_EVALS, STAT_ESCAPED, STAT_CAPTURED, STAT_INVALID = range(6)
+STAT_WORDS = 8
+
+INTEGRATORS = {"dp45": INTEGRATOR_DP45, "rk4": INTEGRATOR_RK4}
+SCHEDULES = {"direct": SCHED_DIRECT, "queue": SCHED_QUEUE}
+
+
+class LtraceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libltrace_hip error {code}: {msg}")
+        self.code = code
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32),
+                ("hfov", C.c_double), ("vfov", C.c_double),
+                ("psi_y", C.c_double), ("psi_x", C.c_double),
+                ("r_obs", C.c_double), ("theta_obs", C.c_double)]
+
+
+class Metric(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("M", C.c_double), ("a", C.c_double)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("integrator", C.c_int32), ("precision", C.c_int32), ("schedule", C.c_int32),
+                ("tb_symmetry", C.c_int32), ("loop_around", C.c_int32), ("row_block", C.c_int32),
+                ("n_parts", C.c_int32), ("part", C.c_int32),
+                ("axis_refine_frac", C.c_double), ("phi_max", C.c_double), ("h_max", C.c_double),
+                ("stream", C.c_void_p), ("timing", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("counters", C.c_uint64 * STAT_WORDS),
+                ("prologue_ms", C.c_double), ("integrate_ms", C.c_double), ("epilogue_ms", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/ltrace.h declares
+SIGNATURES = {
+    "lt_version": (C.c_int, []),
+    "lt_last_error": (C.c_char_p, []),
+    "lt_device_count": (C.c_int, []),
+    "lt_set_device": (C.c_int, [C.c_int]),
+    "lt_shutdown": (C.c_int, []),
+    "lt_default_opts": (None, [C.POINTER(Opts)]),
+    "lt_trace_batch_schw": (C.c_int, [C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_double, C.c_double,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_trace_batch_kerr": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_double,
+                                      C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_kerr_rhs_probe": (C.c_int, [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "lt_local_rows": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "lt_global_row": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "lt_render_dev": (C.c_int, [C.POINTER(Camera), C.POINTER(Metric), C.POINTER(Opts), C.c_void_p, C.c_int32,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_render": (C.c_int, [C.POINTER(Camera), C.POINTER(Metric), C.POINTER(Opts), C.c_void_p, C.c_int32,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.POINTER(Stats)]),
+    "lt_scatter_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_void_p]),
+    "lt_timing_collect": (C.c_int, [_dp, _dp, _dp, C.POINTER(C.c_int32)]),
+    "lt_valu_peak_probe": (C.c_int, [C.c_int, C.c_int, _dp]),
+}
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != OK:
+        raise LtraceError(rc, load().lt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(load().lt_device_count())
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise LtraceError(ERR_NO_DEVICE, "no HIP device visible; this package has no CPU path")
+
+
+def default_opts(**kw):
+    o = Opts()
+    load().lt_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if k == "integrator" and isinstance(v, str):
+            v = INTEGRATORS[v]
+        if k == "schedule" and isinstance(v, str):
+            v = SCHEDULES[v]
+        setattr(o, k, v)
+    return o
+
+
+def _np_ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _out(a, dtype, n, name):
+    if a is None:
+        return None
+    if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous and a.size == n
+            and a.flags.writeable):
+        raise ValueError(f"{name} must be a writable C-contiguous {np.dtype(dtype).name} array of {n} elements")
+    return a
+
+
+def trace_batch_schw(M, r_obs, alphas, out_fa, out_w, phi_max=50.0, h_max=0.05, precision=32,
+                     out_status=None, out_rhs_evals=None):
+    """In-place twin of _trace_rays_batch_schwarzschild (reference metrics.py:661-668)."""
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    n = al.size
+    _out(out_fa, np.float64, n, "out_fa")
+    _out(out_w, np.int64, n, "out_w")
+    _out(out_status, np.int8, n, "out_status")
+    _out(out_rhs_evals, np.uint32, n, "out_rhs_evals")
+    _check(load().lt_trace_batch_schw(M, r_obs, _np_ptr(al), n, phi_max, h_max, precision,
+                                      _np_ptr(out_fa), _np_ptr(out_w), _np_ptr(out_status),
+                                      _np_ptr(out_rhs_evals)))
+
+
+def trace_batch_kerr(M, a, r_obs, alphas, thetas, theta_obs, lambda_max, axis_refines, out_fa, out_w,
+                     integrator=INTEGRATOR_RK4, precision=32, schedule=SCHED_DIRECT,
+                     out_status=None, out_rhs_evals=None):
+    """In-place twin of _trace_rays_batch_kerr (reference metrics.py:671-679)."""
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    th = np.ascontiguousarray(thetas, dtype=np.float64)
+    n = al.size
+    if th.size != n:
+        raise ValueError("alphas and thetas differ in length")
+    ar = None
+    if axis_refines is not None:
+        ar = np.ascontiguousarray(axis_refines).astype(np.uint8)
+        if ar.size != n:
+            raise ValueError("axis_refines has the wrong length")
+    _out(out_fa, np.float64, n, "out_fa")
+    _out(out_w, np.int64, n, "out_w")
+    _out(out_status, np.int8, n, "out_status")
+    _out(out_rhs_evals, np.uint32, n, "out_rhs_evals")
+    if isinstance(integrator, str):
+        integrator = INTEGRATORS[integrator]
+    if isinstance(schedule, str):
+        schedule = SCHEDULES[schedule]
+    _check(load().lt_trace_batch_kerr(M, a, r_obs, _np_ptr(al), _np_ptr(th), theta_obs, lambda_max, _np_ptr(ar),
+                                      integrator, precision, schedule, n, _np_ptr(out_fa), _np_ptr(out_w),
+                                      _np_ptr(out_status), _np_ptr(out_rhs_evals)))
+
+
+def kerr_rhs_probe(M, a, states, p_phi, precision=32):
+    st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 5)
+    pp = np.ascontiguousarray(p_phi, dtype=np.float64).ravel()
+    out = np.empty_like(st)
+    _check(load().lt_kerr_rhs_probe(M, a, _np_ptr(st), _np_ptr(pp), st.shape[0], precision, _np_ptr(out)))
+    return out
+
+
+def local_rows(height, row_block, n_parts, part):
+    return int(load().lt_local_rows(height, row_block, n_parts, part))
+
+
+def global_rows(height, row_block, n_parts, part):
+    """Global row index of every local row of a partition (host helper for tests / gathers)."""
+    n = local_rows(height, row_block, n_parts, part)
+    lib = load()
+    return np.array([lib.lt_global_row(i, row_block, n_parts, part) for i in range(n)], dtype=np.int64)
+
+
+def render(cam, metric, opts, background=None, want=("fa", "winding", "status", "steps", "rgb", "rgba")):
+    """Host-pointer frame render (lt_render).  Returns dict of numpy arrays + 'stats'."""
+    rows = local_rows(cam.height, opts.row_block or 16, opts.n_parts or 1, opts.part)
+    W = cam.width
+    bg = None
+    nch = 3
+    if background is not None:
+        bg = np.ascontiguousarray(background, dtype=np.float32)
+        if bg.shape[:2] != (cam.height, cam.width):
+            raise ValueError("background must have the frame's height and width")
+        nch = 1 if bg.ndim == 2 else bg.shape[2]
+        if nch not in (1, 3):
+            raise ValueError("background must be grayscale or RGB")
+    out = {}
+    if "fa" in want:
+        out["fa"] = np.empty((rows, W), dtype=np.float32)
+    if "winding" in want:
+        out["winding"] = np.empty((rows, W), dtype=np.uint16)
+    if "status" in want:
+        out["status"] = np.empty((rows, W), dtype=np.int8)
+    if "steps" in want:
+        out["steps"] = np.empty((rows, W), dtype=np.uint32)
+    if "rgb" in want:
+        out["rgb"] = np.empty((rows, W) if (bg is not None and bg.ndim == 2) else (rows, W, nch), dtype=np.float32)
+    if "rgba" in want:
+        out["rgba"] = np.empty((rows, W, 4), dtype=np.uint8)
+    st = Stats()
+    _check(load().lt_render(C.byref(cam), C.byref(metric), C.byref(opts), _np_ptr(bg), nch,
+                            _np_ptr(out.get("fa")), _np_ptr(out.get("winding")), _np_ptr(out.get("status")),
+                            _np_ptr(out.get("steps")), _np_ptr(out.get("rgb")), _np_ptr(out.get("rgba")),
+                            C.byref(st)))
+    out["stats"] = stats_dict(st.counters, st.prologue_ms, st.integrate_ms, st.epilogue_ms)
+    return out
+
+
+def stats_dict(counters, prologue_ms=0.0, integrate_ms=0.0, epilogue_ms=0.0):
+    c = [int(x) for x in counters]
+    return dict(rays=c[STAT_RAYS], steps=c[STAT_STEPS], rhs_evals=c[STAT_RHS_EVALS], escaped=c[STAT_ESCAPED],
+                captured=c[STAT_CAPTURED], invalid=c[STAT_INVALID],
+                prologue_ms=prologue_ms, integrate_ms=integrate_ms, epilogue_ms=epilogue_ms)
+
+
+def render_dev(cam, metric, opts, d_bg=0, bg_channels=3, d_fa=0, d_w=0, d_status=0, d_steps=0, d_rgb=0, d_rgba=0,
+               d_stats=0):
+    """Device-pointer frame render (lt_render_dev); pointers are integers (tensor.data_ptr()), 0 = NULL.
+    Asynchronous on opts.stream."""
+    p = lambda x: C.c_void_p(x) if x else None
+    _check(load().lt_render_dev(C.byref(cam), C.byref(metric), C.byref(opts), p(d_bg), bg_channels, p(d_fa), p(d_w),
+                                p(d_status), p(d_steps), p(d_rgb), p(d_rgba), p(d_stats)))
+
+
+def scatter_rows_dev(d_part, d_full, height, width, elem_bytes, row_block, n_parts, part, stream=0):
+    _check(load().lt_scatter_rows_dev(C.c_void_p(d_part), C.c_void_p(d_full), height, width, elem_bytes, row_block,
+                                      n_parts, part, C.c_void_p(stream) if stream else None))
+
+
+def timing_collect():
+    a, b, c = C.c_double(), C.c_double(), C.c_double()
+    n = C.c_int32()
+    _check(load().lt_timing_collect(C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+    return dict(prologue_ms=a.value, integrate_ms=b.value, epilogue_ms=c.value, calls=n.value)
+
+
+def valu_peak_probe(mode=0, iters=4096):
+    t = C.c_double()
+    _check(load().lt_valu_peak_probe(mode, iters, C.byref(t)))
+    return t.value
+
+
+def shutdown():
+    if _lib is not None:
+        _lib.lt_shutdown()

@@ -1,0 +1,107 @@
+"""CPU-side tests of the product package: host physics of metrics.py against the reference's
+scalar known answers, the C-ABI library's symbol table, the row partition, loud failure
+without a GPU.  No GPU compute here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ltrace
+import metrics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def scalars(golden_dir):
+    with open(os.path.join(golden_dir, "scalars.json")) as f:
+        return json.load(f)
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/ltrace.h declares must be exported by libltrace_hip.so."""
+    hdr = open(os.path.join(ROOT, "include", "ltrace.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(ltrace.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in ltrace.h but not exported"
+    assert declared == set(ltrace.SIGNATURES), "ctypes binding and header disagree"
+    assert ltrace.load().lt_version() == 100
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives for the structs in ltrace.h (x86-64 SysV)
+    assert ctypes.sizeof(ltrace.Camera) == 8 + 6 * 8
+    assert ctypes.sizeof(ltrace.Metric) == 8 + 2 * 8
+    assert ctypes.sizeof(ltrace.Opts) == 8 * 4 + 3 * 8 + 8 + 8
+    assert ctypes.sizeof(ltrace.Stats) == 8 * 8 + 3 * 8
+
+
+def test_row_partition_is_a_partition():
+    for H, rb, n in [(4096, 16, 8), (33, 16, 2), (100, 7, 3), (5, 16, 8), (64, 16, 1)]:
+        seen = np.zeros(H, dtype=int)
+        for p in range(n):
+            rows = ltrace.global_rows(H, rb, n, p)
+            assert len(rows) == ltrace.local_rows(H, rb, n, p)
+            assert np.all(np.diff(rows) > 0)
+            seen[rows] += 1
+        assert np.all(seen == 1)
+    assert ltrace.local_rows(64, 16, 4, 7) == -1      # part out of range
+
+
+@pytest.mark.skipif(ltrace.device_count() > 0, reason="GPU present")
+def test_no_gpu_means_loud_failure_not_fallback():
+    fa = np.full(4, np.nan)
+    w = np.zeros(4, dtype=np.int64)
+    with pytest.raises(ltrace.LtraceError) as ei:
+        metrics.Schwarzschild(1.0).trace_rays_batch(50.0, np.linspace(0.05, 0.3, 4), fa, w)
+    assert ei.value.code == ltrace.ERR_NO_DEVICE
+    assert np.all(np.isnan(fa))                      # nothing computed behind our back
+    with pytest.raises(ltrace.LtraceError):
+        metrics.Kerr(1.0, 0.9).trace_ray(50.0, 0.15, 0.7)
+
+
+def test_schwarzschild_scalars(scalars):
+    S = metrics.Schwarzschild(1.0)
+    for r, v in scalars["schw_alpha_crit"].items():
+        assert S.alpha_crit(float(r)) == pytest.approx(v, rel=0, abs=1e-15)
+    assert S.capture_radius() == scalars["schw_capture_radius"]
+    for deg, b in scalars["schw_b"].items():
+        assert S.viewing_angle_to_impact_parameter(np.radians(float(deg)), 50.0) == pytest.approx(b, abs=1e-13)
+    s0 = S.initial_conditions(50.0, 0.15)
+    np.testing.assert_allclose(s0, scalars["schw_ic8"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(S.geodesic_equations(0.0, s0), scalars["schw_rhs8"], rtol=1e-13, atol=1e-18)
+    assert S.is_spherically_symmetric and S.R_S == 2.0 and S.R_PHOTON == 3.0
+
+
+def test_kerr_scalars(scalars):
+    for a_key, rec in scalars["kerr"].items():
+        K = metrics.Kerr(1.0, float(a_key))
+        assert K.r_plus == pytest.approx(rec["r_plus"], abs=1e-15)
+        assert K.capture_radius() == pytest.approx(rec["capture_radius"], abs=1e-15)
+        for r, v in rec["alpha_crit"].items():
+            assert K.alpha_crit(float(r)) == pytest.approx(v, abs=1e-14)
+        assert K.alpha_crit(50.0, 1.0) == pytest.approx(rec["alpha_crit_incl"], abs=1e-14)
+        assert K.viewing_angle_to_impact_parameter(0.15, 50.0) == pytest.approx(rec["b"], abs=1e-12)
+        np.testing.assert_allclose(K._unstable_photon_r(), rec["photon_r"], rtol=1e-14)
+        if "crit" in rec:
+            np.testing.assert_allclose(K._critical_impact_params(), rec["crit"], rtol=1e-12, atol=1e-12)
+    assert not metrics.Kerr.is_spherically_symmetric
+    with pytest.raises(ValueError):
+        metrics.Kerr(1.0, 1.5)                        # reference metrics.py:849-850
+    with pytest.raises(ValueError):
+        metrics.Kerr(1.0, 0.0)._critical_impact_params()
+
+
+def test_kerr_8d_flow_matches_reference(scalars):
+    K = metrics.Kerr(1.0, 0.9)
+    s0 = K.initial_conditions(50.0, 0.15, 0.7)
+    np.testing.assert_allclose(s0, scalars["kerr_ic8"], rtol=1e-13, atol=1e-15)
+    got = K.geodesic_equations(0.0, scalars["kerr_ic8"])
+    np.testing.assert_allclose(got, scalars["kerr_rhs8"], rtol=1e-9, atol=1e-15)
+    assert K.geodesic_equations(0.0, [0, K.r_plus, 1.0, 0, -1, 0, 0, 1]) == [0.0] * 8
