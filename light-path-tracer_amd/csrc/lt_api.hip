@@ -398,6 +398,7 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     unsigned gq = (unsigned)((n_q + 255) / 256);
     int64_t n_pix = (int64_t)c.rows_local * c.W;
     unsigned gp = (unsigned)((n_pix + 255) / 256);
+    if (gp > 4096) gp = 4096; // grid-stride: 16 blocks per CU, one stats flush per block
     FrameOut fo{d_bg, bg_channels, d_fa, d_w, d_status, d_steps, d_rgb, d_rgba, d_stats};
 
     if ((rc = tm.mark(0, s))) return rc;

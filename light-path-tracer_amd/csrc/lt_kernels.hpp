@@ -339,23 +339,29 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
-__device__ __forceinline__ void accumulate_stats(uint64_t *stats, bool counted, const RayResult &o)
+// Per-thread counters, reduced once per block: wave shuffle -> LDS -> six global atomics per
+// block (a first version issued them per wave and the epilogue ran at the atomic rate).
+struct StatAcc {
+    unsigned long long rays = 0, steps = 0, evals = 0, esc = 0, cap = 0, inv = 0;
+    __device__ __forceinline__ void add(const RayResult &o)
+    {
+        rays += 1; steps += o.steps; evals += o.evals;
+        esc += o.status == 1; cap += o.status == -1; inv += o.status == 0;
+    }
+};
+
+__device__ __forceinline__ void flush_stats(uint64_t *stats, const StatAcc &a)
 {
     if (!stats) return;
-    unsigned long long rays = wave_sum(counted ? 1ull : 0ull);
-    unsigned long long steps = wave_sum(counted ? (unsigned long long)o.steps : 0ull);
-    unsigned long long evals = wave_sum(counted ? (unsigned long long)o.evals : 0ull);
-    unsigned long long esc = wave_sum(counted && o.status == 1 ? 1ull : 0ull);
-    unsigned long long cap = wave_sum(counted && o.status == -1 ? 1ull : 0ull);
-    unsigned long long inv = wave_sum(counted && o.status == 0 ? 1ull : 0ull);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd((unsigned long long *)&stats[0], rays);
-        atomicAdd((unsigned long long *)&stats[1], steps);
-        atomicAdd((unsigned long long *)&stats[2], evals);
-        atomicAdd((unsigned long long *)&stats[3], esc);
-        atomicAdd((unsigned long long *)&stats[4], cap);
-        atomicAdd((unsigned long long *)&stats[5], inv);
-    }
+    __shared__ unsigned long long sh[6];
+    if (threadIdx.x < 6) sh[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long v[6] = {wave_sum(a.rays), wave_sum(a.steps), wave_sum(a.evals),
+                               wave_sum(a.esc), wave_sum(a.cap), wave_sum(a.inv)};
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&sh[i], v[i]);
+    __syncthreads();
+    if (threadIdx.x < 6 && sh[threadIdx.x]) atomicAdd((unsigned long long *)&stats[threadIdx.x], sh[threadIdx.x]);
 }
 
 struct FrameOut {
@@ -414,24 +420,22 @@ __device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int
     }
 }
 
-// One thread per local pixel, row-major: every output array is written fully coalesced.
+// Grid-stride over the partition's pixels in row-major order: every output array is written fully
+// coalesced whatever order the integrate kernel finished the rays in.
 template <typename T>
 __global__ void __launch_bounds__(256) k_epilogue_frame(CamConsts c, MetricConsts m,
                                                         const typename Vec4<T>::type *__restrict__ fin0,
                                                         const typename Vec4<T>::type *__restrict__ fin1, FrameOut o)
 {
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t n_pix = (int64_t)c.rows_local * c.W;
-    bool live = p < n_pix;
-    RayResult res;
-    res.status = 0; res.fa = 0; res.n_half = 0; res.steps = 0; res.evals = 0;
-    bool counted = false;
-    if (live) {
+    StatAcc acc;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 256) {
         int lrow = (int)(p / c.W), ix = (int)(p - (int64_t)lrow * c.W);
         int src_row = lrow;
         if (c.use_tb && lrow >= c.H - c.H / 2) src_row = c.H - 1 - lrow; // quirk Q1 (image_lens.py:272-276)
-        counted = (src_row == lrow);
+        RayResult res;
         load_result<T>(m, fin0, fin1, pixel_to_q(c, ix, src_row), res);
+        if (src_row == lrow) acc.add(res); // mirrored pixels are copies, not rays
         float fa32 = (res.status == 1) ? (float)res.fa : __builtin_nanf("");
         long long wl = res.n_half < 0 ? 0 : (res.n_half > 65535 ? 65535 : res.n_half);
         if (o.fa) o.fa[p] = fa32;
@@ -453,7 +457,7 @@ __global__ void __launch_bounds__(256) k_epilogue_frame(CamConsts c, MetricConst
             }
         }
     }
-    accumulate_stats(o.stats, counted, res);
+    flush_stats(o.stats, acc);
 }
 
 // Epilogue of the batch twins: float64 final_alpha, int64 winding (metrics.py:667-668, :678-679).

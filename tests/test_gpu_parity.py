@@ -123,7 +123,8 @@ def test_batch_edge_cases():
         S.trace_rays_batch(50.0, al, fa, w)
         fo, wo, so, _ = oracle.trace_batch_schw(1.0, 50.0, al)
         assert np.array_equal(np.isnan(fa), np.isnan(fo))
-        assert np.nanmax(np.abs(fa - fo)) < 2e-4
+        if n > 1:
+            assert np.nanmax(np.abs(fa - fo)) < 2e-4
         assert np.isnan(fa[0]) and w[0] == 0          # alpha == 0 -> invalid
     # slices of larger buffers, as image_lens.py:172-174 passes them
     big_fa, big_w = np.full(300, np.nan), np.zeros(300, dtype=np.int64)
