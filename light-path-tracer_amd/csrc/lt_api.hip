@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -84,14 +85,17 @@ static int cur_ctx(Ctx **out)
     return LT_OK;
 }
 
-// Workspace layout: ic[n_q] | fin0[n_q] | fin1[n_q], each a 4-vector of T.
-static int get_workspace(size_t n_q, size_t elem, void **ic, void **fin0, void **fin1)
+// Workspace layout: 256 B of control words (queue head) | ic[n_q] | fin0[n_q] | fin1[n_q], each a
+// 4-vector of T.
+struct Workspace { uint32_t *head; void *ic, *fin0, *fin1; };
+
+static int get_workspace(size_t n_q, size_t elem, Workspace *w)
 {
     Ctx *c;
     int rc = cur_ctx(&c);
     if (rc) return rc;
     size_t vec = 4 * elem;
-    size_t need = 3 * n_q * vec;
+    size_t need = 256 + 3 * n_q * vec;
     std::lock_guard<std::mutex> lk(g_mu);
     if (need > c->ws_bytes) {
         if (c->ws) {
@@ -103,9 +107,31 @@ static int get_workspace(size_t n_q, size_t elem, void **ic, void **fin0, void *
         HIP_TRY(hipMalloc(&c->ws, need));
         c->ws_bytes = need;
     }
-    *ic = c->ws;
-    *fin0 = (char *)c->ws + n_q * vec;
-    *fin1 = (char *)c->ws + 2 * n_q * vec;
+    char *base = (char *)c->ws;
+    w->head = (uint32_t *)base;
+    w->ic = base + 256;
+    w->fin0 = base + 256 + n_q * vec;
+    w->fin1 = base + 256 + 2 * n_q * vec;
+    return LT_OK;
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+static int cu_count(int *out)
+{
+    static int cached[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!cached[dev & 63]) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        cached[dev & 63] = prop.multiProcessorCount;
+    }
+    *out = cached[dev & 63];
     return LT_OK;
 }
 
@@ -304,25 +330,68 @@ extern "C" int lt_timing_collect(double *prologue_ms, double *integrate_ms, doub
     return LT_OK;
 }
 
+// Diagnostic wave stamps (LT_STAMPS_FILE=path): one uint4 per wavefront, dumped raw after the launch.
+struct StampDump {
+    const char *path = getenv("LT_STAMPS_FILE");
+    uint4 *dev = nullptr;
+    size_t n = 0;
+    int begin(size_t waves)
+    {
+        if (!path) return LT_OK;
+        n = waves;
+        HIP_TRY(hipMalloc((void **)&dev, n * sizeof(uint4)));
+        HIP_TRY(hipMemset(dev, 0, n * sizeof(uint4)));
+        return LT_OK;
+    }
+    int end()
+    {
+        if (!path) return LT_OK;
+        std::vector<uint4> h(n);
+        HIP_TRY(hipMemcpy(h.data(), dev, n * sizeof(uint4), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(dev));
+        if (FILE *f = fopen(path, "wb")) { fwrite(h.data(), sizeof(uint4), n, f); fclose(f); }
+        return LT_OK;
+    }
+};
+
 template <typename T>
-static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lambda_max, void *ic, void *fin0,
-                            void *fin1, int64_t n_q, hipStream_t s)
+static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lambda_max, const Workspace &w,
+                            int64_t n_q, hipStream_t s)
 {
     using V = typename Vec4<T>::type;
+    int rc;
     unsigned grid = (unsigned)((n_q + 255) / 256);
     if (mc.kind == LT_METRIC_SCHWARZSCHILD) {
         SchwConsts<T> k = make_schw<T>(mc, o.phi_max, o.h_max);
-        k_schw_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)ic, (V *)fin0, (V *)fin1, n_q);
+        k_schw_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q);
     } else {
         KerrConsts<T> k = make_kerr<T>(mc, lambda_max, o.h_max);
-        if (o.integrator == LT_INTEGRATOR_RK4) {
-            if (o.schedule == LT_SCHED_DIRECT)
-                k_kerr_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)ic, (V *)fin0, (V *)fin1, n_q);
-            else
-                return fail(LT_ERR_UNSUPPORTED, "queue schedule not built yet");
+        if (o.integrator != LT_INTEGRATOR_RK4) return fail(LT_ERR_UNSUPPORTED, "DP45 integrator not built yet");
+        StampDump sd;
+        if (o.schedule == LT_SCHED_DIRECT) {
+            static const int k2_block = [] { int b = env_int("LT_K2_BLOCK", 64);
+                                             return (b == 64 || b == 128 || b == 256) ? b : 64; }();
+            unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
+            if ((rc = sd.begin((size_t)(n_q / 64)))) return rc;
+            k_kerr_rk4_direct<T><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, sd.dev);
         } else {
-            return fail(LT_ERR_UNSUPPORTED, "DP45 integrator not built yet");
+            if (n_q >= (int64_t)1 << 32) return fail(LT_ERR_UNSUPPORTED, "queue schedule: more than 2^32 rays");
+            int cus;
+            if ((rc = cu_count(&cus))) return rc;
+            // persistent grid: blocks-per-CU x CUs, never more blocks than there are 256-ray pieces
+            static const int bpc = env_int("LT_Q_BPC", sizeof(T) == 4 ? 8 : 3);
+            static const int chunk = env_int("LT_Q_CHUNK", 64);
+            static const int refill_min = env_int("LT_Q_REFILL", 4);
+            static const int long_steps = env_int("LT_Q_LONG", 600);
+            unsigned qgrid = (unsigned)(cus * bpc);
+            if (qgrid > grid) qgrid = grid;
+            HIP_TRY(hipMemsetAsync(w.head, 0, sizeof(uint32_t), s));
+            if ((rc = sd.begin((size_t)qgrid * 4))) return rc;
+            k_kerr_rk4_queue<T><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint32_t)n_q, w.head,
+                                                      (uint32_t)chunk, (uint32_t)refill_min, (uint32_t)long_steps, sd.dev);
         }
+        HIP_TRY(hipGetLastError());
+        if ((rc = sd.end())) return rc;
     }
     HIP_TRY(hipGetLastError());
     return LT_OK;
@@ -386,13 +455,24 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     c.tiles_x = (c.W + 7) / 8;
     if (c.rows_local <= 0) return LT_OK; // a partition may own no rows
     int tiles_y = (c.trace_rows + 7) / 8;
+    c.tiles_y = tiles_y;
+    { // centre-out tile-row order around the row the BH projects to (image centre if it is behind)
+        double bh_row = front ? c.d[1] / c.d[2] * c.fy + c.half_H : c.half_H; // global pixel row
+        double lrow = bh_row / o.n_parts;                                      // ~ local row of the partition
+        if (!(lrow >= 0)) lrow = 0;
+        if (lrow > c.trace_rows - 1) lrow = c.trace_rows - 1;
+        c.perm_c = (int)lrow / 8;
+        int below = tiles_y - 1 - c.perm_c;
+        c.perm_m = c.perm_c < below ? c.perm_c : below;
+    }
     int64_t n_q = (int64_t)c.tiles_x * tiles_y * 64;
     double lambda_max = fmax(5000.0, 6.0 * cam->r_obs); // metrics.py:1132
 
     hipStream_t s = (hipStream_t)o.stream;
     size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
-    void *ic, *fin0, *fin1;
-    if ((rc = get_workspace((size_t)n_q, elem, &ic, &fin0, &fin1))) return rc;
+    Workspace w;
+    if ((rc = get_workspace((size_t)n_q, elem, &w))) return rc;
+    void *ic = w.ic, *fin0 = w.fin0, *fin1 = w.fin1;
     Timer tm;
     if ((rc = tm.begin(o.timing != 0))) return rc;
     unsigned gq = (unsigned)((n_q + 255) / 256);
@@ -406,8 +486,8 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     else k_prologue_camera<double><<<gq, 256, 0, s>>>(c, mc, (double4 *)ic, n_q);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.mark(1, s))) return rc;
-    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, ic, fin0, fin1, n_q, s)
-                           : launch_integrate<double>(mc, o, lambda_max, ic, fin0, fin1, n_q, s);
+    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, w, n_q, s)
+                           : launch_integrate<double>(mc, o, lambda_max, w, n_q, s);
     if (rc) return rc;
     if ((rc = tm.mark(2, s))) return rc;
     if (o.precision == 32) k_epilogue_frame<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
@@ -488,8 +568,9 @@ static int trace_batch(const MetricConsts &mc, lt_opts &o, double lambda_max, co
     if (mc.kind == LT_METRIC_KERR && !thetas) return fail(LT_ERR_INVALID_ARG, "Kerr needs thetas");
     int64_t n_q = (n + 63) / 64 * 64;
     size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
-    void *ic, *fin0, *fin1;
-    if ((rc = get_workspace((size_t)n_q, elem, &ic, &fin0, &fin1))) return rc;
+    Workspace w;
+    if ((rc = get_workspace((size_t)n_q, elem, &w))) return rc;
+    void *ic = w.ic, *fin0 = w.fin0, *fin1 = w.fin1;
     hipStream_t s = nullptr;
     DevBuf dal, dth, dref, dfa, dw, dst, dev;
     if ((rc = dal.alloc(n * 8))) return rc;
@@ -513,8 +594,8 @@ static int trace_batch(const MetricConsts &mc, lt_opts &o, double lambda_max, co
         k_prologue_arrays<double><<<gq, 256, 0, s>>>(mc, (const double *)dal.p, (const double *)dth.p,
                                                      (const uint8_t *)dref.p, n, (double4 *)ic, n_q);
     HIP_TRY(hipGetLastError());
-    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, ic, fin0, fin1, n_q, s)
-                           : launch_integrate<double>(mc, o, lambda_max, ic, fin0, fin1, n_q, s);
+    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, w, n_q, s)
+                           : launch_integrate<double>(mc, o, lambda_max, w, n_q, s);
     if (rc) return rc;
     unsigned gn = (unsigned)((n + 255) / 256);
     if (o.precision == 32)

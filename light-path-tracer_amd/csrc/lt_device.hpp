@@ -204,52 +204,60 @@ __device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, T r, T lam, bool
 }
 
 // Event codes carried from the integrate kernel to the epilogue.
-enum : int { EV_MAXRANGE = 2, EV_ESCAPED = 1, EV_CAPTURED = -1, EV_INVALID = 0, EV_PAD = 3 };
+enum : int { EV_MAXRANGE = 2, EV_ESCAPED = 1, EV_CAPTURED = -1, EV_INVALID = 0, EV_PAD = 3, EV_RUNNING = 4 };
 
-// One ray of the fixed-step RK4 tracer (metrics.py:570-658), from its initial state to the event.
-// Returns the event code; y holds the final (interpolated) state, steps the RK4 steps taken
-// (including halved retries).
-template <typename T>
-__device__ __forceinline__ int kerr_rk4_trace(const KerrConsts<T> &k, const RayConsts<T> &rc, State5<T> &y,
-                                              bool refine, uint32_t &steps)
+// Everything one ray carries between steps (registers).
+template <typename T> struct RayState {
+    State5<T> y;
+    T lam;       // affine parameter so far
+    T h_retry;   // > 0: retry the step with this (halved) h, metrics.py:615-626
+    uint32_t steps;
+};
+
+template <typename T> __device__ __forceinline__ void ray_start(const KerrConsts<T> &k, RayState<T> &s, T p_r, T p_th)
 {
-    T lam = T(0);
-    int ev = EV_MAXRANGE;
-    T h_floor = M<T>::min(refine ? T(0.01) : T(0.02), refine ? M<T>::min(k.h_max, T(0.5)) : k.h_max);
-    T h_retry = T(0);
-    steps = 0;
-    while (lam < k.lambda_max) {
-        T h = (h_retry > T(0)) ? h_retry : kerr_rk4_h(k, y.r, lam, refine);
-        if (!(h > T(0))) break;
-        State5<T> n = kerr_rk4_step(k, rc, y, h);
-        ++steps;
-        bool ok = M<T>::finite(n.r) && M<T>::finite(n.th) && M<T>::finite(n.ph) && M<T>::finite(n.pr) &&
-                  M<T>::finite(n.pth) && n.r > T(0);
-        if (!ok) {
-            if (h <= h_floor) { ev = EV_INVALID; break; }
-            h_retry = T(0.5) * h;
-            continue;
-        }
-        h_retry = T(0);
-        bool cap = y.r > k.r_capture && n.r <= k.r_capture;
-        bool esc = !cap && y.r < k.r_escape && n.r >= k.r_escape;
-        if (cap || esc) {
-            T target = cap ? k.r_capture : k.r_escape;
-            T denom = n.r - y.r;
-            T frac = (denom == T(0)) ? T(1) : (target - y.r) / denom;
-            frac = M<T>::min(M<T>::max(frac, T(0)), T(1));
-            y.r = M<T>::fma(frac, n.r - y.r, y.r);
-            y.th = M<T>::fma(frac, n.th - y.th, y.th);
-            y.ph = M<T>::fma(frac, n.ph - y.ph, y.ph);
-            y.pr = M<T>::fma(frac, n.pr - y.pr, y.pr);
-            y.pth = M<T>::fma(frac, n.pth - y.pth, y.pth);
-            ev = cap ? EV_CAPTURED : EV_ESCAPED;
-            break;
-        }
-        y = n;
-        lam += h;
+    s.y.r = k.r_obs; s.y.th = k.theta_obs; s.y.ph = T(0); s.y.pr = p_r; s.y.pth = p_th;
+    s.lam = T(0); s.h_retry = T(0); s.steps = 0;
+}
+
+// One iteration of the reference's fixed-step RK4 tracer (metrics.py:596-655): choose h, take an RK4
+// step, halve-and-retry on a non-finite result, stop on the capture / escape crossing with the
+// reference's linear interpolation.  Returns EV_RUNNING or the terminating event.  Both schedules of
+// the integrate kernel call exactly this function, so they produce bit-identical results.
+template <typename T>
+__device__ __forceinline__ int kerr_rk4_advance(const KerrConsts<T> &k, const RayConsts<T> &rc, RayState<T> &s, bool refine)
+{
+    if (!(s.lam < k.lambda_max)) return EV_MAXRANGE;
+    T h = (s.h_retry > T(0)) ? s.h_retry : kerr_rk4_h(k, s.y.r, s.lam, refine);
+    if (!(h > T(0))) return EV_MAXRANGE;
+    State5<T> n = kerr_rk4_step(k, rc, s.y, h);
+    ++s.steps;
+    bool ok = M<T>::finite(n.r) && M<T>::finite(n.th) && M<T>::finite(n.ph) && M<T>::finite(n.pr) &&
+              M<T>::finite(n.pth) && n.r > T(0);
+    if (!ok) {
+        T h_floor = M<T>::min(refine ? T(0.01) : T(0.02), refine ? M<T>::min(k.h_max, T(0.5)) : k.h_max);
+        if (h <= h_floor) return EV_INVALID;
+        s.h_retry = T(0.5) * h;
+        return EV_RUNNING;
     }
-    return ev;
+    s.h_retry = T(0);
+    bool cap = s.y.r > k.r_capture && n.r <= k.r_capture;
+    bool esc = !cap && s.y.r < k.r_escape && n.r >= k.r_escape;
+    if (cap || esc) {
+        T target = cap ? k.r_capture : k.r_escape;
+        T denom = n.r - s.y.r;
+        T frac = (denom == T(0)) ? T(1) : (target - s.y.r) / denom;
+        frac = M<T>::min(M<T>::max(frac, T(0)), T(1));
+        s.y.r = M<T>::fma(frac, n.r - s.y.r, s.y.r);
+        s.y.th = M<T>::fma(frac, n.th - s.y.th, s.y.th);
+        s.y.ph = M<T>::fma(frac, n.ph - s.y.ph, s.y.ph);
+        s.y.pr = M<T>::fma(frac, n.pr - s.y.pr, s.y.pr);
+        s.y.pth = M<T>::fma(frac, n.pth - s.y.pth, s.y.pth);
+        return cap ? EV_CAPTURED : EV_ESCAPED;
+    }
+    s.y = n;
+    s.lam += h;
+    return EV_RUNNING;
 }
 
 // ---------------------------------------------------------------------------------------

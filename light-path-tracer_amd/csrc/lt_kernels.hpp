@@ -30,7 +30,8 @@ struct CamConsts {
     int rows_local;      // rows this partition owns
     int trace_rows;      // rows actually traced (tb_symmetry: (H+1)/2), n_parts == 1 only
     int use_tb;          // 1: rows >= H - H/2 copy row H-1-j (reference quirk Q1)
-    int tiles_x;
+    int tiles_x, tiles_y;
+    int perm_c, perm_m;  // centre-out tile-row order: centre row, number of symmetric pairs
     int row_block, n_parts, part;
     int loop_around;
     double half_W, half_H, fx, fy; // x_cam = (ix - W/2) / fx  (image_lens.py:141-142)
@@ -51,18 +52,40 @@ __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
     return (b * c.n_parts + c.part) * c.row_block + o;
 }
 
+// Tile rows are queued centre-out from the row the black hole projects to (perm_c): position 0 is
+// row c, then c+1, c-1, c+2, ...; once one side is used up (perm_m pairs) the other continues.  The
+// rays that orbit near the critical curve -- up to ~50x the mean step count, a serial chain nothing
+// can shorten -- are therefore the first to start instead of forming the tail of the launch.
+__device__ __forceinline__ int queue_pos_to_tile_row(const CamConsts &c, int p)
+{
+    if (p <= 2 * c.perm_m) {
+        int kk = (p + 1) >> 1;
+        return (p & 1) ? c.perm_c + kk : c.perm_c - kk;
+    }
+    int rest = p - 2 * c.perm_m;
+    return (c.perm_c + c.perm_m + 1 < c.tiles_y) ? c.perm_c + c.perm_m + rest : c.perm_c - c.perm_m - rest;
+}
+
+__device__ __forceinline__ int tile_row_to_queue_pos(const CamConsts &c, int ty)
+{
+    int d = ty - c.perm_c, ad = d < 0 ? -d : d;
+    if (ad <= c.perm_m) return d > 0 ? 2 * d - 1 : 2 * ad;
+    return 2 * c.perm_m + (ad - c.perm_m);
+}
+
 __device__ __forceinline__ void q_to_pixel(const CamConsts &c, int64_t q, int &ix, int &lrow)
 {
     int lane = (int)(q & 63);
     int64_t tile = q >> 6;
-    int ty = (int)(tile / c.tiles_x), tx = (int)(tile - (int64_t)ty * c.tiles_x);
+    int p = (int)(tile / c.tiles_x), tx = (int)(tile - (int64_t)p * c.tiles_x);
+    int ty = queue_pos_to_tile_row(c, p);
     ix = tx * 8 + (lane & 7);
     lrow = ty * 8 + (lane >> 3);
 }
 
 __device__ __forceinline__ int64_t pixel_to_q(const CamConsts &c, int ix, int lrow)
 {
-    int64_t tile = (int64_t)(lrow >> 3) * c.tiles_x + (ix >> 3);
+    int64_t tile = (int64_t)tile_row_to_queue_pos(c, lrow >> 3) * c.tiles_x + (ix >> 3);
     return (tile << 6) | ((lrow & 7) << 3) | (ix & 7);
 }
 
@@ -190,6 +213,23 @@ __global__ void __launch_bounds__(256) k_prologue_arrays(MetricConsts m, const d
     }
 }
 
+// Diagnostic wave stamps (off unless LT_STAMPS_FILE is set): {start, end} of the 100 MHz real-time
+// counter, HW_ID (CU / SE / SIMD), XCC_ID -- one record per wavefront, never read by any kernel.
+__device__ __forceinline__ uint64_t wave_clock() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void write_stamp(uint4 *stamps, int64_t wave, uint64_t t0, uint32_t steps)
+{
+    uint32_t max_steps = steps;
+    for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(max_steps, off, 64); max_steps = o > max_steps ? o : max_steps; }
+    uint64_t t1 = wave_clock();
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+        uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
+        uint4 v;
+        v.x = (uint32_t)t0; v.y = (uint32_t)(t1 - t0); v.z = hw; v.w = (xcc & 0xf) | (max_steps << 4);
+        stamps[wave] = v;
+    }
+}
+
 // ---- K2: integrate --------------------------------------------------------------------------
 // Final record: fin0 = (r, theta, phi, p_r), fin1 = (p_theta, p_phi, event, steps)   [Kerr]
 //               fin0 = (u, w, phi_last, full_steps), fin1 = (0, 0, event, steps)      [Schwarzschild]
@@ -208,21 +248,110 @@ __device__ __forceinline__ void store_fin(typename Vec4<T>::type *fin0, typename
 template <typename T>
 __global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
-                                                         typename Vec4<T>::type *__restrict__ fin1, int64_t n_q)
+                                                         typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
+                                                         uint4 *__restrict__ stamps)
 {
-    int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
+    uint64_t t0 = stamps ? wave_clock() : 0;
     typename Vec4<T>::type rec = ic[q];
     int flags = (int)rec.w;
-    State5<T> y;
-    y.r = k.r_obs; y.th = k.theta_obs; y.ph = T(0); y.pr = rec.x; y.pth = rec.y;
+    RayState<T> st;
+    ray_start(k, st, rec.x, rec.y);
     int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
-    uint32_t steps = 0;
     if (flags & FLAG_OK) {
         RayConsts<T> rc = make_ray_consts(k, rec.z);
-        ev = kerr_rk4_trace(k, rc, y, (flags & FLAG_REFINE) != 0, steps);
+        bool refine = (flags & FLAG_REFINE) != 0;
+        do { ev = kerr_rk4_advance(k, rc, st, refine); } while (ev == EV_RUNNING);
     }
-    store_fin<T>(fin0, fin1, q, y.r, y.th, y.ph, y.pr, y.pth, rec.z, ev, steps);
+    uint32_t steps = st.steps;
+    store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
+    if (stamps) write_stamp(stamps, q >> 6, t0, steps);
+}
+
+// Queue schedule: persistent wavefronts.  The grid is sized to fill the chip once (blocks = CUs x
+// blocks-per-CU) and never relies on the dispatcher again.  Each wavefront owns a private chunk
+// [next, end) of the ray queue, reserved with ONE atomic per chunk by one lane; lanes whose ray has
+// terminated are refilled from the chunk by ballot + prefix count (v_mbcnt), so consecutive queue
+// entries -- an 8x8 pixel tile -- still land in the same wavefront.  No LDS, no barriers, no
+// inter-wave traffic other than the queue head; every wave reaches the exit (queue drained and all
+// of its lanes idle).  A wave hosting a very long ray (a photon orbiting near the critical curve:
+// up to ~50x the mean step count) raises its issue priority so that the serial chain of that one
+// ray is not time-sliced 8 ways against bulk work.
+template <typename T>
+__global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k, const typename Vec4<T>::type *__restrict__ ic,
+                                                        typename Vec4<T>::type *__restrict__ fin0,
+                                                        typename Vec4<T>::type *__restrict__ fin1, uint32_t n_q,
+                                                        uint32_t *__restrict__ head, uint32_t chunk,
+                                                        uint32_t refill_min, uint32_t long_steps,
+                                                        uint4 *__restrict__ stamps)
+{
+    uint64_t t0 = stamps ? wave_clock() : 0;
+    uint32_t next = 0, end = 0; // wave-uniform: this wave's chunk
+    bool drained = false;       // wave-uniform: the global queue is empty
+    bool have = false;          // this lane holds a live ray
+    bool refine = false;
+    uint32_t q = 0, total_steps = 0;
+    int prio = 0;
+    RayState<T> st;
+    RayConsts<T> rc;
+    ray_start(k, st, T(0), T(0));
+    rc = make_ray_consts(k, T(0));
+    for (;;) {
+        uint64_t idle = __ballot(!have);
+        uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle && !drained && (n_idle >= refill_min || n_idle == 64u)) {
+            // ---- refill idle lanes from the wave's chunk; reserve a new chunk when it runs out
+            for (;;) {
+                if (next >= end) {
+                    uint32_t base = 0;
+                    if ((threadIdx.x & 63) == 0) base = atomicAdd(head, chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= n_q) { drained = true; break; }
+                    next = base;
+                    end = (n_q - base < chunk) ? n_q : base + chunk;
+                }
+                idle = __ballot(!have);
+                n_idle = (uint32_t)__popcll(idle);
+                if (!n_idle) break;
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                uint32_t avail = end - next;
+                if (!have && rank < avail) {
+                    q = next + rank;
+                    typename Vec4<T>::type rec = ic[q];
+                    int flags = (int)rec.w;
+                    if (flags & FLAG_OK) {
+                        ray_start(k, st, rec.x, rec.y);
+                        rc = make_ray_consts(k, rec.z);
+                        refine = (flags & FLAG_REFINE) != 0;
+                        have = true;
+                    } else { // padding or no valid initial condition: finished before it starts
+                        store_fin<T>(fin0, fin1, q, k.r_obs, k.theta_obs, T(0), rec.x, rec.y, rec.z,
+                                     (flags & FLAG_PAD) ? EV_PAD : EV_INVALID, 0u);
+                    }
+                }
+                next += (n_idle < avail) ? n_idle : avail;
+            }
+        }
+        if (!__ballot(have)) {
+            if (drained) break;
+            continue;
+        }
+        if (have) {
+            int ev = kerr_rk4_advance(k, rc, st, refine);
+            if (ev != EV_RUNNING) {
+                store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
+                total_steps += st.steps;
+                have = false;
+            }
+        }
+        int want = __ballot(have && st.steps > long_steps) ? 3 : 0;
+        if (want != prio) {
+            prio = want;
+            if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    if (stamps) write_stamp(stamps, (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), t0, total_steps);
 }
 
 template <typename T>
