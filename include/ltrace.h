@@ -180,6 +180,15 @@ int lt_timing_collect(double *prologue_ms, double *integrate_ms, double *epilogu
  * FMA blocks per lane; mode 0 = v_fma_f32, 1 = v_pk_fma_f32.  Returns achieved TFLOP/s in *tflops. */
 int lt_valu_peak_probe(int mode, int iters, double *tflops);
 
+/* VALU issue-cost microbenchmark (diagnostic; DESIGN.md "issue-rate roofline"): instruction class
+ * `index` in [0, lt_valu_issue_probe_count()), `waves_per_simd` resident waves per SIMD (1..8).
+ * constant_data != 0 runs it on all-equal operands (no datapath toggling: highest clock).
+ * Returns ns per wave-instruction per SIMD and the shader clock the chip held during the loop
+ * (s_memtime / s_memrealtime); name_out receives the instruction mnemonic. */
+int lt_valu_issue_probe(int index, int waves_per_simd, int iters, int constant_data, char *name_out,
+                        int name_len, double *ns_per_instr, double *clock_mhz);
+int lt_valu_issue_probe_count(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 // HIP events.  No CPU compute path exists: without a GPU the entry points fail.
 #include "../../include/ltrace.h"
 #include "lt_kernels.hpp"
+#include "lt_probe.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -714,3 +715,44 @@ extern "C" int lt_valu_peak_probe(int mode, int iters, double *tflops)
     if (tflops) *tflops = flops / (ms * 1e-3) / 1e12;
     return LT_OK;
 }
+
+// VALU issue-cost probe: instruction class `index` (see lt_probe.hpp), `waves_per_simd` resident waves
+// per SIMD (1..8) on every CU.  Reports the kernel time and the number of wave-instructions each SIMD
+// issued, i.e. ns per wave-instruction per SIMD (multiply by the shader clock for cycles).
+extern "C" int lt_valu_issue_probe(int index, int waves_per_simd, int iters, int constant_data, char *name_out,
+                                   int name_len, double *ns_per_instr, double *clock_mhz)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (index < 0 || index >= g_n_probes) return fail(LT_ERR_INVALID_ARG, "probe index %d out of range [0,%d)", index, g_n_probes);
+    if (waves_per_simd < 1 || waves_per_simd > 8) return fail(LT_ERR_INVALID_ARG, "waves_per_simd must be 1..8");
+    const ProbeEntry &pe = g_probes[index];
+    if (name_out && name_len > 0) snprintf(name_out, (size_t)name_len, "%s", pe.name);
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    DevBuf sink;
+    if ((rc = sink.alloc(64))) return rc;
+    unsigned grid = (unsigned)(cus * waves_per_simd);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    float sc = constant_data ? 0.0f : 0.999f;
+    pe.kernel<<<grid, 256>>>(8, sc, (float *)sink.p);
+    HIP_TRY(hipEventRecord(e0, 0));
+    pe.kernel<<<grid, 256>>>(iters, sc, (float *)sink.p);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    double instr_per_simd = (double)iters * 64.0 * pe.instr_per_body * waves_per_simd; // 8 bodies x 8 chains
+    if (ns_per_instr) *ns_per_instr = ms * 1e6 / instr_per_simd;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(h, sink.p, sizeof(h), hipMemcpyDeviceToHost));
+    if (clock_mhz) *clock_mhz = h[3] ? (double)h[2] / (double)h[3] * 100.0 : 0.0; // s_memtime / s_memrealtime(100 MHz)
+    return LT_OK;
+}
+
+extern "C" int lt_valu_issue_probe_count(void) { return g_n_probes; }

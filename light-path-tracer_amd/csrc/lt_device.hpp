@@ -1,14 +1,18 @@
 // lt_device.hpp -- __device__ building blocks of the gfx950 ray integrators.
 //
-// Written for CDNA4 wave64: everything a ray needs lives in registers, the metric
-// terms are inlined, there is no LDS and no cross-lane traffic in the hot loop.
+// Written for CDNA4 wave64: everything a ray needs lives in registers, the metric terms are
+// inlined, there is no LDS and no cross-lane traffic in the hot loop.
 //
-// What each block computes is fixed by the reference (cited per function); HOW it is
-// computed is not a transcription: the Kerr right-hand side is re-derived from the
-// separable form of the Hamiltonian so that one evaluation costs ~70 VALU
-// instructions instead of the reference's 186 flops + 14 divides, while remaining the
-// exact gradient of the same H (so it agrees with the reference for any state, on- or
-// off-shell -- tests/test_gpu_parity.py::test_kerr_rhs_probe).
+// What each block computes is fixed by the reference (cited per function); HOW it is computed is
+// not a transcription.  The integrate kernel is VALU-issue bound, and on gfx950 (measured with
+// tools/issue_probe.py) every VALU instruction costs ~2.1 issue cycles per wave
+// when FMA-class and "second pipe" instructions (min/max/cmp/cvt/select, anything with an SGPR
+// operand) are mixed, a transcendental (v_rcp_f32 ...) costs ~13, and a packed v_pk_* costs two
+// plain ones.  So the design rule is: fewest instructions, fewest reciprocals.  The Kerr
+// right-hand side is re-derived from the separable form of the Hamiltonian (one merged reciprocal,
+// ~75 instructions instead of the reference's 186 flops + 14 divides) while remaining the exact
+// gradient of the same H, so it agrees with the reference for any state, on- or off-shell
+// (tests/test_gpu_parity.py::test_kerr_rhs_probe_matches_reference).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,12 +20,12 @@
 namespace lt {
 
 // ---------------------------------------------------------------------------------------
-// scalar math wrappers: float uses hardware rcp/sqrt + one Newton step and a bounded-range
-// polynomial sincos; double uses the OCML routines.
+// scalar math wrappers
 // ---------------------------------------------------------------------------------------
 template <typename T> struct M;
 
 template <> struct M<float> {
+    // 1/x: hardware reciprocal (1 ulp) + one Newton step
     static __device__ __forceinline__ float rcp(float x)
     {
         float y = __builtin_amdgcn_rcpf(x);
@@ -32,13 +36,16 @@ template <> struct M<float> {
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
-    // sin and cos of an angle of modest size (|x| < ~1e4; the polar angle of a ray stays within
-    // a few pi).  Cody-Waite reduction by pi/2 in three pieces, then the classic single-precision
-    // minimax polynomials on [-pi/4, pi/4]: ~22 full-rate VALU ops for both values, ~1 ulp.
+    // sin^2 floored at 1e-15 (metrics.py:236-237): below float resolution unless sin^2 < 1e-8, so an
+    // add does the job of the max without leaving the FMA pipe.
+    static __device__ __forceinline__ float sin2_floor(float s) { return __builtin_fmaf(s, s, 1e-15f); }
+    // sin and cos of an angle of modest size (|x| < ~1e4; the polar angle of a ray stays within a
+    // few pi).  Cody-Waite reduction by pi/2 in three pieces, single-precision minimax polynomials
+    // on [-pi/4, pi/4], quadrant fix-up with integer ops: ~25 VALU ops for both values, ~1 ulp.
     static __device__ __forceinline__ void sincos(float x, float &s, float &c)
     {
         const float TWO_OVER_PI = 0.636619772367581343f;
-        const float P1 = 1.5703125f;                 // pi/2 split: 8 + 11 + 24 significant bits
+        const float P1 = 1.5703125f; // pi/2 split: 8 + 11 + 24 significant bits
         const float P2 = 4.837512969970703125e-4f;
         const float P3 = 7.54978995489188e-8f;
         float kf = __builtin_rintf(x * TWO_OVER_PI);
@@ -56,10 +63,14 @@ template <> struct M<float> {
         bool swap = k & 1;
         float ss = swap ? cy : sy;
         float cc = swap ? sy : cy;
-        s = (k & 2) ? -ss : ss;
-        c = ((k + 1) & 2) ? -cc : cc;
+        // sign: sin flips for k = 2,3 (mod 4), cos for k = 1,2
+        uint32_t sbit = ((uint32_t)k << 30) & 0x80000000u;
+        uint32_t cbit = ((uint32_t)(k + 1) << 30) & 0x80000000u;
+        s = __uint_as_float(__float_as_uint(ss) ^ sbit);
+        c = __uint_as_float(__float_as_uint(cc) ^ cbit);
     }
-    static __device__ __forceinline__ bool finite(float x) { return __builtin_isfinite(x); }
+    // true unless x is NaN or +-inf
+    static __device__ __forceinline__ bool finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 };
 
 template <> struct M<double> {
@@ -68,8 +79,9 @@ template <> struct M<double> {
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double sin2_floor(double s) { return __builtin_fmax(s * s, 1e-15); }
     static __device__ __forceinline__ void sincos(double x, double &s, double &c) { ::sincos(x, &s, &c); }
-    static __device__ __forceinline__ bool finite(double x) { return __builtin_isfinite(x); }
+    static __device__ __forceinline__ bool finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 };
 
 // ---------------------------------------------------------------------------------------
@@ -88,19 +100,27 @@ template <typename T> struct KerrConsts {
     T rc4, rc2, rc12; // r_capture * 4, * 2, * 1.2 (metrics.py:606-611)
 };
 
-// Per-ray constants derived from the conserved p_phi = L (p_t = -1 throughout, metrics.py:187).
+// Per-ray constants: the conserved p_phi = L (p_t = -1 throughout, metrics.py:187), what follows
+// from it, and the ray's step-size table (axis-refine rays use tighter caps, metrics.py:591-611).
 template <typename T> struct RayConsts {
     T L;
-    T c_P;   // a^2 - a L          ->  P = r^2 + c_P        (P = (r^2+a^2) E - a L, E = 1)
-    T c_W;   // -2 a L             ->  W = L^2/s2 + c_W + a^2 s2
+    T c_P;   // a^2 - a L   ->  P = r^2 + c_P        (P = (r^2 + a^2) E - a L, E = 1)
+    T c_W;   // -2 a L      ->  W = L^2/s2 + c_W + a^2 s2
+    T hb, h4, h2, h12, h_floor; // base step, the three radius-band caps, the retry floor
 };
 
-template <typename T> __device__ __forceinline__ RayConsts<T> make_ray_consts(const KerrConsts<T> &k, T L)
+template <typename T>
+__device__ __forceinline__ RayConsts<T> make_ray_consts(const KerrConsts<T> &k, T L, bool refine)
 {
     RayConsts<T> rc;
     rc.L = L;
     rc.c_P = M<T>::fma(-k.a, L, k.a2);
     rc.c_W = T(-2) * k.a * L;
+    rc.hb = refine ? M<T>::min(k.h_max, T(0.5)) : k.h_max;
+    rc.h4 = M<T>::min(rc.hb, refine ? T(0.20) : T(0.25));
+    rc.h2 = M<T>::min(rc.hb, refine ? T(0.08) : T(0.10));
+    rc.h12 = M<T>::min(rc.hb, refine ? T(0.03) : T(0.05));
+    rc.h_floor = M<T>::min(refine ? T(0.01) : T(0.02), rc.hb);
     return rc;
 }
 
@@ -111,20 +131,28 @@ template <typename T> __device__ __forceinline__ RayConsts<T> make_ray_consts(co
 //     W = L^2/sin^2 - 2 a L + a^2 sin^2,   P = r^2 + a^2 - a L,
 // so dx/dlambda = dH/dp and dp/dlambda = -dH/dx = -(F_x - 2H Sigma_x) / (2 Sigma).  The 2H term is
 // zero on a null geodesic but is kept: the reference differentiates the full H, and integration
-// error drives H slightly off zero.  sin^2(theta) is floored at 1e-15 as in metrics.py:236-237.
+// error drives H slightly off zero.  The three reciprocals 1/Sigma, 1/Delta, 1/sin^2 come from ONE
+// hardware reciprocal of their product.  At or inside r_cut the reference returns zeros
+// (metrics.py:228-231): every output carries the factor 1/Sigma, so masking that one factor (and
+// evaluating at max(r, r_cut) so nothing overflows) does it.
 template <typename T>
-__device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts<T> &rc, T r, T th, T pr, T pth,
+__device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T th, T pr, T pth,
                                          T &dr, T &dth, T &dph, T &dpr, T &dpth)
 {
     T s, c;
     M<T>::sincos(th, s, c);
-    T s2 = M<T>::max(s * s, T(1e-15));
+    bool inside = r_in <= k.r_cut;
+    T r = inside ? k.r_cut : r_in;
+    T s2 = M<T>::sin2_floor(s);
     T r2 = r * r;
     T Sigma = M<T>::fma(k.a2 * c, c, r2);
     T Delta = M<T>::fma(-k.two_M, r, r2) + k.a2;
-    T iS = M<T>::rcp(Sigma);
-    T iD = M<T>::rcp(Delta);
-    T is2 = M<T>::rcp(s2);
+    T SD = Sigma * Delta;
+    T t = M<T>::rcp(SD * s2);
+    T iS = (Delta * s2) * t;
+    T iD = (Sigma * s2) * t;
+    T is2 = SD * t;
+    iS = inside ? T(0) : iS;
     T P = r2 + rc.c_P;
     T q = P * iD;
     T Lis2 = rc.L * is2;
@@ -132,28 +160,24 @@ __device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts
     T pr2 = pr * pr;
     T F = M<T>::fma(Delta, pr2, M<T>::fma(pth, pth, M<T>::fma(-P, q, W)));
     T H2 = F * iS;
-    T o_dr = Delta * pr * iS;
-    T o_dth = pth * iS;
-    T o_dph = iS * M<T>::fma(k.a, q, Lis2 - k.a);
-    T Dr = M<T>::fma(T(2), r, -k.two_M);
-    T Fr = M<T>::fma(Dr, M<T>::fma(q, q, pr2), T(-4) * r * q);
-    T o_dpr = T(-0.5) * iS * M<T>::fma(-H2, T(2) * r, Fr);
-    T sc = s * c;
+    T iSpr = iS * pr;
+    dr = Delta * iSpr;
+    dth = pth * iS;
+    dph = iS * M<T>::fma(k.a, q, Lis2 - k.a);
+    T two_r = r + r;
+    T Fr = M<T>::fma(two_r - k.two_M, M<T>::fma(q, q, pr2), T(-2) * two_r * q);
+    T mhiS = T(-0.5) * iS;
+    dpr = mhiS * M<T>::fma(-H2, two_r, Fr);
     // F_theta = 2 s c (a^2 - L^2/s^4),  Sigma_theta = -2 a^2 s c
-    T o_dpth = -iS * sc * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2));
-    bool inside = r <= k.r_cut;
-    dr = inside ? T(0) : o_dr;
-    dth = inside ? T(0) : o_dth;
-    dph = inside ? T(0) : o_dph;
-    dpr = inside ? T(0) : o_dpr;
-    dpth = inside ? T(0) : o_dpth;
+    dpth = (T(2) * mhiS) * (s * c) * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2));
 }
 
 template <typename T> struct State5 {
     T r, th, ph, pr, pth;
 };
 
-// Classic RK4 step, metrics.py:306-323.
+// Classic RK4 step, metrics.py:306-323 (phi does not enter the right-hand side, so the stage states
+// carry only r, theta, p_r, p_theta).
 template <typename T>
 __device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const RayConsts<T> &rc,
                                                    const State5<T> &y, T h)
@@ -186,21 +210,16 @@ __device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const
     return o;
 }
 
-// Step-size rule of the reference's fixed-step RK4 tracer (metrics.py:591-611): h_base, capped
-// in three radius bands around the capture radius; tighter caps on axis-refine rays.
+// Step-size rule of the reference's fixed-step RK4 tracer (metrics.py:597-611): h_base capped by
+// the remaining affine range and by the innermost radius band the ray is in.  The bands are nested
+// and the caps decrease inwards, so the cascade of min() of the reference is a 3-way select.
 template <typename T>
-__device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, T r, T lam, bool refine)
+__device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, const RayConsts<T> &rc, T r, T lam)
 {
-    T h = refine ? M<T>::min(k.h_max, T(0.5)) : k.h_max;
-    T remaining = k.lambda_max - lam;
-    h = remaining < h ? remaining : h;
-    T c4 = refine ? T(0.20) : T(0.25);
-    T c2 = refine ? T(0.08) : T(0.10);
-    T c12 = refine ? T(0.03) : T(0.05);
-    h = (r < k.rc4) ? M<T>::min(h, c4) : h;
-    h = (r < k.rc2) ? M<T>::min(h, c2) : h;
-    h = (r < k.rc12) ? M<T>::min(h, c12) : h;
-    return h;
+    T h = (r < k.rc4) ? rc.h4 : rc.hb;
+    h = (r < k.rc2) ? rc.h2 : h;
+    h = (r < k.rc12) ? rc.h12 : h;
+    return M<T>::min(h, k.lambda_max - lam);
 }
 
 // Event codes carried from the integrate kernel to the epilogue.
@@ -224,27 +243,28 @@ template <typename T> __device__ __forceinline__ void ray_start(const KerrConsts
 // step, halve-and-retry on a non-finite result, stop on the capture / escape crossing with the
 // reference's linear interpolation.  Returns EV_RUNNING or the terminating event.  Both schedules of
 // the integrate kernel call exactly this function, so they produce bit-identical results.
+//
 template <typename T>
-__device__ __forceinline__ int kerr_rk4_advance(const KerrConsts<T> &k, const RayConsts<T> &rc, RayState<T> &s, bool refine)
+__device__ __forceinline__ int kerr_rk4_advance(const KerrConsts<T> &k, const RayConsts<T> &rc, RayState<T> &s)
 {
     if (!(s.lam < k.lambda_max)) return EV_MAXRANGE;
-    T h = (s.h_retry > T(0)) ? s.h_retry : kerr_rk4_h(k, s.y.r, s.lam, refine);
+    T h = (s.h_retry > T(0)) ? s.h_retry : kerr_rk4_h(k, rc, s.y.r, s.lam);
     if (!(h > T(0))) return EV_MAXRANGE;
     State5<T> n = kerr_rk4_step(k, rc, s.y, h);
     ++s.steps;
-    bool ok = M<T>::finite(n.r) && M<T>::finite(n.th) && M<T>::finite(n.ph) && M<T>::finite(n.pr) &&
-              M<T>::finite(n.pth) && n.r > T(0);
+    // all five components finite <=> the sum of their magnitudes is (NaN and inf both propagate)
+    T mag = M<T>::abs(n.r) + M<T>::abs(n.th) + M<T>::abs(n.ph) + M<T>::abs(n.pr) + M<T>::abs(n.pth);
+    bool ok = M<T>::finite(mag) && n.r > T(0);
     if (!ok) {
-        T h_floor = M<T>::min(refine ? T(0.01) : T(0.02), refine ? M<T>::min(k.h_max, T(0.5)) : k.h_max);
-        if (h <= h_floor) return EV_INVALID;
+        if (h <= rc.h_floor) return EV_INVALID;
         s.h_retry = T(0.5) * h;
         return EV_RUNNING;
     }
     s.h_retry = T(0);
-    bool cap = s.y.r > k.r_capture && n.r <= k.r_capture;
-    bool esc = !cap && s.y.r < k.r_escape && n.r >= k.r_escape;
-    if (cap || esc) {
-        T target = cap ? k.r_capture : k.r_escape;
+    bool cap_first = n.r <= k.r_capture && s.y.r > k.r_capture; // the reference tests capture first
+    bool esc = !cap_first && n.r >= k.r_escape && s.y.r < k.r_escape;
+    if (cap_first || esc) {
+        T target = cap_first ? k.r_capture : k.r_escape;
         T denom = n.r - s.y.r;
         T frac = (denom == T(0)) ? T(1) : (target - s.y.r) / denom;
         frac = M<T>::min(M<T>::max(frac, T(0)), T(1));
@@ -253,7 +273,7 @@ __device__ __forceinline__ int kerr_rk4_advance(const KerrConsts<T> &k, const Ra
         s.y.ph = M<T>::fma(frac, n.ph - s.y.ph, s.y.ph);
         s.y.pr = M<T>::fma(frac, n.pr - s.y.pr, s.y.pr);
         s.y.pth = M<T>::fma(frac, n.pth - s.y.pth, s.y.pth);
-        return cap ? EV_CAPTURED : EV_ESCAPED;
+        return cap_first ? EV_CAPTURED : EV_ESCAPED;
     }
     s.y = n;
     s.lam += h;
@@ -273,8 +293,8 @@ template <typename T> struct SchwConsts {
     T h_last;        // remaining partial step (0 if none)
 };
 
-// Returns the event code; u, w are the final values, phi_frac the part of the last step used
-// (phi_f = steps_before * h + phi_frac is rebuilt in float64 by the epilogue).
+// Returns the event code; u, w are the final values, phi_last the part of the last step used
+// (phi_f = steps_before * h + phi_last is rebuilt in float64 by the epilogue).
 template <typename T>
 __device__ __forceinline__ int schw_trace(const SchwConsts<T> &k, T &u, T &w, uint32_t &steps, T &phi_last)
 {

@@ -260,9 +260,8 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k, const 
     ray_start(k, st, rec.x, rec.y);
     int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
     if (flags & FLAG_OK) {
-        RayConsts<T> rc = make_ray_consts(k, rec.z);
-        bool refine = (flags & FLAG_REFINE) != 0;
-        do { ev = kerr_rk4_advance(k, rc, st, refine); } while (ev == EV_RUNNING);
+        RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
+        do { ev = kerr_rk4_advance(k, rc, st); } while (ev == EV_RUNNING);
     }
     uint32_t steps = st.steps;
     store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
@@ -290,13 +289,12 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k, const t
     uint32_t next = 0, end = 0; // wave-uniform: this wave's chunk
     bool drained = false;       // wave-uniform: the global queue is empty
     bool have = false;          // this lane holds a live ray
-    bool refine = false;
     uint32_t q = 0, total_steps = 0;
     int prio = 0;
     RayState<T> st;
     RayConsts<T> rc;
     ray_start(k, st, T(0), T(0));
-    rc = make_ray_consts(k, T(0));
+    rc = make_ray_consts(k, T(0), false);
     for (;;) {
         uint64_t idle = __ballot(!have);
         uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -322,8 +320,7 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k, const t
                     int flags = (int)rec.w;
                     if (flags & FLAG_OK) {
                         ray_start(k, st, rec.x, rec.y);
-                        rc = make_ray_consts(k, rec.z);
-                        refine = (flags & FLAG_REFINE) != 0;
+                        rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
                         have = true;
                     } else { // padding or no valid initial condition: finished before it starts
                         store_fin<T>(fin0, fin1, q, k.r_obs, k.theta_obs, T(0), rec.x, rec.y, rec.z,
@@ -338,7 +335,7 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k, const t
             continue;
         }
         if (have) {
-            int ev = kerr_rk4_advance(k, rc, st, refine);
+            int ev = kerr_rk4_advance(k, rc, st);
             if (ev != EV_RUNNING) {
                 store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
                 total_steps += st.steps;
@@ -613,7 +610,7 @@ __global__ void k_kerr_rhs_probe(KerrConsts<T> k, const double *__restrict__ sta
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    RayConsts<T> rc = make_ray_consts(k, (T)p_phi[i]);
+    RayConsts<T> rc = make_ray_consts(k, (T)p_phi[i], false);
     T dr, dth, dph, dpr, dpth;
     kerr_rhs<T>(k, rc, (T)states[i * 5 + 0], (T)states[i * 5 + 1], (T)states[i * 5 + 3], (T)states[i * 5 + 4],
                 dr, dth, dph, dpr, dpth);

@@ -82,6 +82,8 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, C.c_void_p]),
     "lt_timing_collect": (C.c_int, [_dp, _dp, _dp, C.POINTER(C.c_int32)]),
     "lt_valu_peak_probe": (C.c_int, [C.c_int, C.c_int, _dp]),
+    "lt_valu_issue_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _dp, _dp]),
+    "lt_valu_issue_probe_count": (C.c_int, []),
 }
 
 
@@ -268,6 +270,19 @@ def valu_peak_probe(mode=0, iters=4096):
     t = C.c_double()
     _check(load().lt_valu_peak_probe(mode, iters, C.byref(t)))
     return t.value
+
+
+def valu_issue_probe(index, waves_per_simd=8, iters=2000, constant_data=False):
+    """-> (mnemonic, ns per wave-instruction per SIMD, shader clock in MHz during the loop)"""
+    name = C.create_string_buffer(64)
+    t, clk = C.c_double(), C.c_double()
+    _check(load().lt_valu_issue_probe(index, waves_per_simd, iters, int(constant_data), name, 64,
+                                      C.byref(t), C.byref(clk)))
+    return name.value.decode(), t.value, clk.value
+
+
+def valu_issue_probe_count():
+    return int(load().lt_valu_issue_probe_count())
 
 
 def shutdown():
