@@ -188,6 +188,13 @@ int lt_valu_peak_probe(int mode, int iters, double *tflops);
 int lt_valu_issue_probe(int index, int waves_per_simd, int iters, int constant_data, char *name_out,
                         int name_len, double *ns_per_instr, double *clock_mhz);
 int lt_valu_issue_probe_count(void);
+/* The Kerr RK4 step alone (no events, no divergence), `iters` times per lane, `waves_per_simd`
+ * resident waves per SIMD: shader cycles one SIMD spends per wave-step, and the clock held. */
+/* Pieces of the right-hand side (0 sincos, 1 the rest, 2 the rest without the reciprocal): SIMD
+ * cycles per evaluation per wave. */
+int lt_piece_probe(int piece, int waves_per_simd, int iters, double *cycles_per_eval, double *clock_mhz);
+int lt_rk4_step_probe(int precision, int waves_per_simd, int iters, double *cycles_per_wave_step,
+                      double *clock_mhz);
 
 #ifdef __cplusplus
 }

@@ -756,3 +756,94 @@ extern "C" int lt_valu_issue_probe(int index, int waves_per_simd, int iters, int
 }
 
 extern "C" int lt_valu_issue_probe_count(void) { return g_n_probes; }
+
+// RK4-step issue probe: `iters` steps of the Kerr RK4 step per lane at `waves_per_simd` resident waves
+// per SIMD.  Returns shader cycles per step per wave-slot-on-a-SIMD (i.e. elapsed cycles x
+// waves_per_simd / iters ... divided back out: cycles one SIMD spends per wave-step) and the clock.
+extern "C" int lt_rk4_step_probe(int precision, int waves_per_simd, int iters, double *cycles_per_wave_step,
+                                 double *clock_mhz)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (waves_per_simd < 1 || waves_per_simd > 8) return fail(LT_ERR_INVALID_ARG, "waves_per_simd must be 1..8");
+    lt_metric m{LT_METRIC_KERR, 0, 1.0, 0.9};
+    MetricConsts mc;
+    if ((rc = make_metric(&m, 50.0, M_PI / 2, 0.0, &mc))) return rc;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    DevBuf out;
+    if ((rc = out.alloc(256))) return rc;
+    unsigned grid = (unsigned)(cus * waves_per_simd);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        if (rep) HIP_TRY(hipEventRecord(e0, 0));
+        if (precision == 32)
+            k_probe_rk4_step<float><<<grid, 256>>>(make_kerr<float>(mc, 5000.0, 1.0), rep ? iters : 16, 0.01f, (float *)out.p);
+        else
+            k_probe_rk4_step<double><<<grid, 256>>>(make_kerr<double>(mc, 5000.0, 1.0), rep ? iters : 16, 0.01, (double *)out.p);
+    }
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // the in-kernel stamps come from the oldest wave, which wins issue arbitration: use them for the
+    // clock only, and the launch's wall time for the throughput
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+    double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    if (clock_mhz) *clock_mhz = mhz;
+    if (cycles_per_wave_step) *cycles_per_wave_step = (double)ms * 1e-3 * mhz * 1e6 / ((double)iters * waves_per_simd);
+    return LT_OK;
+}
+
+// Piece probe (diagnostic): PIECE 0 sincos, 1 right-hand side without sincos, 2 the same without the
+// reciprocal, 3 the two polynomials alone; 4 evaluations per loop iteration.  Returns SIMD cycles per
+// evaluation per wave.
+#include "lt_probe_pieces.hpp"
+extern "C" int lt_piece_probe(int piece, int waves_per_simd, int iters, double *cycles_per_eval, double *clock_mhz)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    lt_metric m{LT_METRIC_KERR, 0, 1.0, 0.9};
+    MetricConsts mc;
+    if ((rc = make_metric(&m, 50.0, M_PI / 2, 0.0, &mc))) return rc;
+    int cus;
+    if ((rc = cu_count(&cus))) return rc;
+    DevBuf out;
+    if ((rc = out.alloc(256))) return rc;
+    unsigned grid = (unsigned)(cus * waves_per_simd);
+    KerrConsts<float> k = make_kerr<float>(mc, 5000.0, 1.0);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        int it = rep ? iters : 16;
+        if (rep) HIP_TRY(hipEventRecord(e0, 0));
+        if (piece == 0) k_probe_piece<0><<<grid, 256>>>(k, it, (float *)out.p);
+        else if (piece == 1) k_probe_piece<1><<<grid, 256>>>(k, it, (float *)out.p);
+        else if (piece == 2) k_probe_piece<2><<<grid, 256>>>(k, it, (float *)out.p);
+        else if (piece == 3) k_probe_piece<3><<<grid, 256>>>(k, it, (float *)out.p);
+        else if (piece == 4) k_probe_piece<4><<<grid, 256>>>(k, it, (float *)out.p);
+        else if (piece == 5) k_probe_piece<5><<<grid, 256>>>(k, it, (float *)out.p);
+        else if (piece == 6) k_probe_piece<6><<<grid, 256>>>(k, it, (float *)out.p);
+        else k_probe_piece<7><<<grid, 256>>>(k, it, (float *)out.p);
+    }
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    unsigned long long h[2] = {0, 0};
+    HIP_TRY(hipMemcpy(h, out.p, sizeof(h), hipMemcpyDeviceToHost));
+    double mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    if (clock_mhz) *clock_mhz = mhz;
+    if (cycles_per_eval) *cycles_per_eval = (double)ms * 1e-3 * mhz * 1e6 / ((double)iters * 4.0 * waves_per_simd);
+    return LT_OK;
+}

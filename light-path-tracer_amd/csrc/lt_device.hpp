@@ -32,6 +32,19 @@ template <> struct M<float> {
         float e = __builtin_fmaf(-x, y, 1.0f);
         return __builtin_fmaf(y, e, y);
     }
+    // 1/x for positive normal x WITHOUT the transcendental unit.  Measured on gfx950 (lt_piece_probe):
+    // one v_rcp_f32 inside this kernel's FMA-dense stream costs ~70 SIMD cycles, whatever the
+    // occupancy and whether or not anything depends on it, against ~13 for six FMA-class instructions.
+    // Bit trick seed (relative error <= 5.1 %), one cubic and one quadratic Newton step: error 1.7e-8
+    // before rounding, i.e. correctly rounded to within 1 ulp like rcp + Newton.
+    static __device__ __forceinline__ float rcp_pos(float x)
+    {
+        float y = __uint_as_float(0x7EF311C0u - __float_as_uint(x));
+        float e = __builtin_fmaf(-x, y, 1.0f);
+        y = __builtin_fmaf(y, __builtin_fmaf(e, e, e), y);
+        e = __builtin_fmaf(-x, y, 1.0f);
+        return __builtin_fmaf(y, e, y);
+    }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -75,6 +88,7 @@ template <> struct M<float> {
 
 template <> struct M<double> {
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double rcp_pos(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
@@ -100,13 +114,28 @@ template <typename T> struct KerrConsts {
     T rc4, rc2, rc12; // r_capture * 4, * 2, * 1.2 (metrics.py:606-611)
 };
 
+// A VALU instruction with an SGPR source runs on the half-rate pipe on gfx950 (v_fma_f32 with an
+// SGPR operand: 4.1 issue cycles against 2.2; tools/issue_probe.py).  The constants the right-hand
+// side multiplies with are therefore copied into VGPRs once per kernel; the empty asm makes the
+// compiler forget that they are wave-uniform.
+#ifndef LT_PIN_CONSTS
+#define LT_PIN_CONSTS 1
+#endif
+template <typename T> __device__ __forceinline__ void pin_consts(KerrConsts<T> &k)
+{
+#if LT_PIN_CONSTS
+    asm volatile("" : "+v"(k.a), "+v"(k.a2), "+v"(k.two_M));
+#endif
+}
+
 // Per-ray constants: the conserved p_phi = L (p_t = -1 throughout, metrics.py:187), what follows
 // from it, and the ray's step-size table (axis-refine rays use tighter caps, metrics.py:591-611).
 template <typename T> struct RayConsts {
     T L;
     T c_P;   // a^2 - a L   ->  P = r^2 + c_P        (P = (r^2 + a^2) E - a L, E = 1)
     T c_W;   // -2 a L      ->  W = L^2/s2 + c_W + a^2 s2
-    T hb, h4, h2, h12, h_floor; // base step, the three radius-band caps, the retry floor
+    T hb;        // base step: h_max, or min(h_max, 0.5) on axis-refine rays (metrics.py:591-593)
+    bool refine; // axis-refine ray: tighter radius-band caps and retry floor
 };
 
 template <typename T>
@@ -117,10 +146,7 @@ __device__ __forceinline__ RayConsts<T> make_ray_consts(const KerrConsts<T> &k, 
     rc.c_P = M<T>::fma(-k.a, L, k.a2);
     rc.c_W = T(-2) * k.a * L;
     rc.hb = refine ? M<T>::min(k.h_max, T(0.5)) : k.h_max;
-    rc.h4 = M<T>::min(rc.hb, refine ? T(0.20) : T(0.25));
-    rc.h2 = M<T>::min(rc.hb, refine ? T(0.08) : T(0.10));
-    rc.h12 = M<T>::min(rc.hb, refine ? T(0.03) : T(0.05));
-    rc.h_floor = M<T>::min(refine ? T(0.01) : T(0.02), rc.hb);
+    rc.refine = refine;
     return rc;
 }
 
@@ -148,7 +174,7 @@ __device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts
     T Sigma = M<T>::fma(k.a2 * c, c, r2);
     T Delta = M<T>::fma(-k.two_M, r, r2) + k.a2;
     T SD = Sigma * Delta;
-    T t = M<T>::rcp(SD * s2);
+    T t = M<T>::rcp_pos(SD * s2); // > 0: r >= r_cut > r_plus so Delta > 0, Sigma > 0, s2 >= 1e-15
     T iS = (Delta * s2) * t;
     T iD = (Sigma * s2) * t;
     T is2 = SD * t;
@@ -210,16 +236,22 @@ __device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const
     return o;
 }
 
-// Step-size rule of the reference's fixed-step RK4 tracer (metrics.py:597-611): h_base capped by
-// the remaining affine range and by the innermost radius band the ray is in.  The bands are nested
-// and the caps decrease inwards, so the cascade of min() of the reference is a 3-way select.
+// Step-size rule of the reference's fixed-step RK4 tracer (metrics.py:597-611): h_base, capped in
+// three radius bands around the capture radius (tighter caps on axis-refine rays) and by the
+// remaining affine range.  Rays spend most of their steps far outside the outermost band
+// (r >= 4 r_capture), and a wavefront is an 8x8 pixel tile, so whether ANY lane is inside is decided
+// per wave and the band cascade is skipped otherwise.
 template <typename T>
-__device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, const RayConsts<T> &rc, T r, T lam)
+__device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, const RayConsts<T> &rc, T r, T remaining)
 {
-    T h = (r < k.rc4) ? rc.h4 : rc.hb;
-    h = (r < k.rc2) ? rc.h2 : h;
-    h = (r < k.rc12) ? rc.h12 : h;
-    return M<T>::min(h, k.lambda_max - lam);
+    T h = rc.hb;
+    if (__ballot(r < k.rc4) != 0ull) {
+        T c4 = rc.refine ? T(0.20) : T(0.25), c2 = rc.refine ? T(0.08) : T(0.10), c12 = rc.refine ? T(0.03) : T(0.05);
+        h = (r < k.rc4) ? M<T>::min(h, c4) : h;
+        h = (r < k.rc2) ? M<T>::min(h, c2) : h;
+        h = (r < k.rc12) ? M<T>::min(h, c12) : h;
+    }
+    return M<T>::min(h, remaining);
 }
 
 // Event codes carried from the integrate kernel to the epilogue.
@@ -244,19 +276,37 @@ template <typename T> __device__ __forceinline__ void ray_start(const KerrConsts
 // reference's linear interpolation.  Returns EV_RUNNING or the terminating event.  Both schedules of
 // the integrate kernel call exactly this function, so they produce bit-identical results.
 //
+// Structure: the arithmetic is straight-line; whether every active lane took an ordinary step (no
+// retry, no crossing, range not exhausted) is decided ONCE per wave with a ballot, so the hot path
+// is one scalar branch instead of a nest of exec-mask regions; the per-lane logic of the rare cases
+// sits behind it.
 template <typename T>
 __device__ __forceinline__ int kerr_rk4_advance(const KerrConsts<T> &k, const RayConsts<T> &rc, RayState<T> &s)
 {
-    if (!(s.lam < k.lambda_max)) return EV_MAXRANGE;
-    T h = (s.h_retry > T(0)) ? s.h_retry : kerr_rk4_h(k, rc, s.y.r, s.lam);
-    if (!(h > T(0))) return EV_MAXRANGE;
+    T remaining = k.lambda_max - s.lam;
+    T h = kerr_rk4_h(k, rc, s.y.r, remaining);
+    if (__builtin_expect(__ballot(s.h_retry > T(0)) != 0ull, 0)) h = (s.h_retry > T(0)) ? s.h_retry : h;
+    bool live = remaining > T(0); // then h > 0 too: every candidate for h is positive
+    // (a lane whose range is exhausted still computes the step -- at most once per ray -- and drops it)
     State5<T> n = kerr_rk4_step(k, rc, s.y, h);
-    ++s.steps;
     // all five components finite <=> the sum of their magnitudes is (NaN and inf both propagate)
     T mag = M<T>::abs(n.r) + M<T>::abs(n.th) + M<T>::abs(n.ph) + M<T>::abs(n.pr) + M<T>::abs(n.pth);
     bool ok = M<T>::finite(mag) && n.r > T(0);
+    // strictly between the capture and the escape radius: neither crossing test of the reference fires
+    bool between = n.r > k.r_capture && n.r < k.r_escape;
+    bool plain = live && ok && between;
+    if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
+        s.y = n;
+        s.lam += h;
+        s.h_retry = T(0);
+        ++s.steps;
+        return EV_RUNNING;
+    }
+    if (!live) return EV_MAXRANGE;
+    ++s.steps;
     if (!ok) {
-        if (h <= rc.h_floor) return EV_INVALID;
+        T h_floor = M<T>::min(rc.refine ? T(0.01) : T(0.02), rc.hb); // metrics.py:594
+        if (h <= h_floor) return EV_INVALID;
         s.h_retry = T(0.5) * h;
         return EV_RUNNING;
     }

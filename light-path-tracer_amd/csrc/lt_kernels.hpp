@@ -246,7 +246,7 @@ __device__ __forceinline__ void store_fin(typename Vec4<T>::type *fin0, typename
 
 // Direct schedule: one work-item per ray, a wavefront = one 8x8 tile.
 template <typename T>
-__global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k, const typename Vec4<T>::type *__restrict__ ic,
+__global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
                                                          uint4 *__restrict__ stamps)
@@ -254,6 +254,8 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k, const 
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
     uint64_t t0 = stamps ? wave_clock() : 0;
+    KerrConsts<T> k = k_in;
+    pin_consts(k);
     typename Vec4<T>::type rec = ic[q];
     int flags = (int)rec.w;
     RayState<T> st;
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k, const 
 // up to ~50x the mean step count) raises its issue priority so that the serial chain of that one
 // ray is not time-sliced 8 ways against bulk work.
 template <typename T>
-__global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k, const typename Vec4<T>::type *__restrict__ ic,
+__global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                         typename Vec4<T>::type *__restrict__ fin0,
                                                         typename Vec4<T>::type *__restrict__ fin1, uint32_t n_q,
                                                         uint32_t *__restrict__ head, uint32_t chunk,
@@ -286,6 +288,8 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k, const t
                                                         uint4 *__restrict__ stamps)
 {
     uint64_t t0 = stamps ? wave_clock() : 0;
+    KerrConsts<T> k = k_in;
+    pin_consts(k);
     uint32_t next = 0, end = 0; // wave-uniform: this wave's chunk
     bool drained = false;       // wave-uniform: the global queue is empty
     bool have = false;          // this lane holds a live ray
@@ -615,6 +619,29 @@ __global__ void k_kerr_rhs_probe(KerrConsts<T> k, const double *__restrict__ sta
     kerr_rhs<T>(k, rc, (T)states[i * 5 + 0], (T)states[i * 5 + 1], (T)states[i * 5 + 3], (T)states[i * 5 + 4],
                 dr, dth, dph, dpr, dpth);
     out[i * 5 + 0] = dr; out[i * 5 + 1] = dth; out[i * 5 + 2] = dph; out[i * 5 + 3] = dpr; out[i * 5 + 4] = dpth;
+}
+
+// Issue-efficiency probe: the RK4 step alone -- no events, no divergence, no refill -- iterated on
+// every lane.  Comparing its cycles per step with the integrate kernel's separates what the
+// arithmetic costs from what the control flow around it costs (lt_rk4_step_probe).
+template <typename T>
+__global__ void __launch_bounds__(256) k_probe_rk4_step(KerrConsts<T> k_in, int iters, T h, T *__restrict__ out)
+{
+    KerrConsts<T> k = k_in;
+    pin_consts(k);
+    int lane = threadIdx.x & 63;
+    RayConsts<T> rc = make_ray_consts(k, T(3) + T(0.01) * (T)lane, false);
+    State5<T> y;
+    y.r = T(20) + T(0.1) * (T)lane; y.th = T(1.0) + T(0.01) * (T)lane; y.ph = T(0); y.pr = T(-0.9); y.pth = T(0.1);
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) y = kerr_rk4_step(k, rc, y, h);
+    unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    T sum = y.r + y.th + y.ph + y.pr + y.pth;
+    if (sum == T(12345.678)) out[8] = sum;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ((unsigned long long *)out)[0] = c1 - c0;
+        ((unsigned long long *)out)[1] = r1 - r0;
+    }
 }
 
 // Row scatter after the multi-GPU gather: partition rows -> full frame, 16 B per lane where possible.

@@ -83,6 +83,29 @@ namespace lt {
 #define I_P5(N) "v_fma_f32 %" #N ", %" #N ", %8, %9\n\tv_fma_f32 %" #N ", %" #N ", %8, %9\n\tv_fma_f32 %" #N ", %" #N ", %8, %9\n\tv_cvt_i32_f32 %" #N ", %" #N
 #define I_P6(N) "v_fma_f32 %" #N ", %" #N ", %8, %9\n\tv_rcp_f32 %" #N ", %" #N "\n\tv_fma_f32 %" #N ", %" #N ", %8, %9\n\tv_max_f32 %" #N ", %" #N ", %9"
 #define I_P7(N) "v_max_f32 %" #N ", %" #N ", %9\n\tv_rcp_f32 %" #N ", %" #N
+// dependent chains: every instruction reads the previous one's result (N ignored)
+#define I_DEP_FMA(N) "v_fma_f32 %0, %0, %8, %9"
+#define I_DEP_FMA_MAX(N) "v_fma_f32 %0, %0, %8, %9\n\tv_max_f32 %0, %0, %9"
+#define I_DEP_MAX(N) "v_max_f32 %0, %0, %9"
+#define I_DEP_FMA_RCP(N) "v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %0, %0, %8, %9\n\tv_rcp_f32 %0, %0"
+#define I_DEP2_FMA(N) "v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9"
+#define I_DEP_MUL(N) "v_mul_f32 %0, %0, %8"
+LT_PROBE_KERNEL(k_probe_dep_fma, I_DEP_FMA)
+LT_PROBE_KERNEL(k_probe_dep_fma_max, I_DEP_FMA_MAX)
+LT_PROBE_KERNEL(k_probe_dep_max, I_DEP_MAX)
+LT_PROBE_KERNEL(k_probe_dep_fma_rcp, I_DEP_FMA_RCP)
+LT_PROBE_KERNEL(k_probe_dep2_fma, I_DEP2_FMA)
+LT_PROBE_KERNEL(k_probe_dep_mul, I_DEP_MUL)
+#define I_RCPD0(N) "v_rcp_f32 %0, %0\n\tv_fma_f32 %0, %0, %8, %9"
+LT_PROBE_KERNEL(k_probe_rcpd0, I_RCPD0)
+#define I_RCPD3(N) "v_rcp_f32 %0, %0\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %0, %0, %8, %9"
+LT_PROBE_KERNEL(k_probe_rcpd3, I_RCPD3)
+#define I_RCPD7(N) "v_rcp_f32 %0, %0\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %0, %0, %8, %9"
+LT_PROBE_KERNEL(k_probe_rcpd7, I_RCPD7)
+#define I_RCPD14(N) "v_rcp_f32 %0, %0\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %0, %0, %8, %9"
+LT_PROBE_KERNEL(k_probe_rcpd14, I_RCPD14)
+#define I_RCPD28(N) "v_rcp_f32 %0, %0\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\tv_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9\n\tv_fma_f32 %0, %0, %8, %9"
+LT_PROBE_KERNEL(k_probe_rcpd28, I_RCPD28)
 LT_PROBE_KERNEL(k_probe_fma, I_FMA)
 LT_PROBE_KERNEL(k_probe_p1, I_P1)
 LT_PROBE_KERNEL(k_probe_p2, I_P2)
@@ -147,6 +170,13 @@ static const ProbeEntry g_probes[] = {
     {"v_add_u32", k_probe_addu, 1}, {"v_bfi_b32", k_probe_bfi, 1}, {"v_fmamk_f32", k_probe_fmamk, 1},
     {"v_med3_f32", k_probe_med3, 1}, {"rcp+2fma", k_probe_rcp_fma2, 3}, {"7xfma+rcp", k_probe_fma7_rcp, 8},
     {"fma+cmp", k_probe_fma_cmp, 2},
+    {"dep fma", k_probe_dep_fma, 1}, {"dep fma,max", k_probe_dep_fma_max, 2}, {"dep max", k_probe_dep_max, 1},
+    {"dep 3fma,rcp", k_probe_dep_fma_rcp, 4}, {"2 chains fma", k_probe_dep2_fma, 2}, {"dep mul", k_probe_dep_mul, 1},
+    {"rcp,0fma,dep-fma", k_probe_rcpd0, 2},
+    {"rcp,3fma,dep-fma", k_probe_rcpd3, 5},
+    {"rcp,7fma,dep-fma", k_probe_rcpd7, 9},
+    {"rcp,14fma,dep-fma", k_probe_rcpd14, 16},
+    {"rcp,28fma,dep-fma", k_probe_rcpd28, 30},
     {"fma+max", k_probe_p1, 2}, {"2fma+max", k_probe_p2, 3}, {"fma+mul(sgpr)", k_probe_p3, 2},
     {"cmp+cnd+2fma", k_probe_p4, 4}, {"3fma+cvt", k_probe_p5, 4}, {"fma+rcp+fma+max", k_probe_p6, 4}, {"max+rcp", k_probe_p7, 2},
 };

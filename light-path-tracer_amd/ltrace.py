@@ -84,6 +84,8 @@ SIGNATURES = {
     "lt_valu_peak_probe": (C.c_int, [C.c_int, C.c_int, _dp]),
     "lt_valu_issue_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _dp, _dp]),
     "lt_valu_issue_probe_count": (C.c_int, []),
+    "lt_rk4_step_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp]),
+    "lt_piece_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp]),
 }
 
 
@@ -279,6 +281,19 @@ def valu_issue_probe(index, waves_per_simd=8, iters=2000, constant_data=False):
     _check(load().lt_valu_issue_probe(index, waves_per_simd, iters, int(constant_data), name, 64,
                                       C.byref(t), C.byref(clk)))
     return name.value.decode(), t.value, clk.value
+
+
+def rk4_step_probe(precision=32, waves_per_simd=8, iters=20000):
+    """-> (shader cycles one SIMD spends per wave-step of the bare Kerr RK4 step, clock MHz)"""
+    c, clk = C.c_double(), C.c_double()
+    _check(load().lt_rk4_step_probe(precision, waves_per_simd, iters, C.byref(c), C.byref(clk)))
+    return c.value, clk.value
+
+
+def piece_probe(piece, waves_per_simd=8, iters=20000):
+    c, clk = C.c_double(), C.c_double()
+    _check(load().lt_piece_probe(piece, waves_per_simd, iters, C.byref(c), C.byref(clk)))
+    return c.value, clk.value
 
 
 def valu_issue_probe_count():
