@@ -457,14 +457,36 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     if (c.rows_local <= 0) return LT_OK; // a partition may own no rows
     int tiles_y = (c.trace_rows + 7) / 8;
     c.tiles_y = tiles_y;
-    { // centre-out tile-row order around the row the BH projects to (image centre if it is behind)
-        double bh_row = front ? c.d[1] / c.d[2] * c.fy + c.half_H : c.half_H; // global pixel row
-        double lrow = bh_row / o.n_parts;                                      // ~ local row of the partition
-        if (!(lrow >= 0)) lrow = 0;
-        if (lrow > c.trace_rows - 1) lrow = c.trace_rows - 1;
-        c.perm_c = (int)lrow / 8;
-        int below = tiles_y - 1 - c.perm_c;
-        c.perm_m = c.perm_c < below ? c.perm_c : below;
+    { // "hot" tile rectangle, queued first: bounds the critical curve (largest impact parameter of a
+      // spherical photon orbit: the retrograde equatorial one for Kerr, 3 sqrt(3) M for a = 0), + margin
+        c.hot_x0 = c.hot_x1 = c.hot_y0 = c.hot_y1 = 0;
+        if (front) {
+            double a = mc.a, M_ = mc.M;
+            double b_max = 3.0 * sqrt(3.0) * M_;
+            if (a != 0.0) { // Bardeen: r_ret = 2M (1 + cos(2/3 acos(|a|/M))), xi(r) as in metrics.py:886-887
+                double aa = fabs(a);
+                double r_ph = 2.0 * M_ * (1.0 + cos(2.0 / 3.0 * acos(aa / M_)));
+                double Dl = r_ph * r_ph - 2.0 * M_ * r_ph + aa * aa;
+                double xi = (r_ph * r_ph + aa * aa) / aa - 2.0 * r_ph * Dl / (aa * (r_ph - M_));
+                if (fabs(xi) > b_max) b_max = fabs(xi);
+            }
+            b_max = 1.05 * b_max + 0.3 * M_;
+            double f0 = 1.0 - 2.0 * M_ / cam->r_obs;
+            double sin_al = f0 > 0 ? b_max * sqrt(f0) / cam->r_obs : 1.0;
+            if (sin_al < 0.98) {
+                double tan_al = sin_al / sqrt(1.0 - sin_al * sin_al);
+                double bx = c.d[0] / c.d[2] * c.fx + c.half_W, by = c.d[1] / c.d[2] * c.fy + c.half_H; // BH pixel
+                double rx = tan_al * c.fx + 8.0, ry = tan_al * c.fy + 8.0;                             // pixels
+                auto clampi = [](double v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : (int)v); };
+                c.hot_x0 = clampi(floor((bx - rx) / 8.0), 0, c.tiles_x);
+                c.hot_x1 = clampi(ceil((bx + rx) / 8.0), 0, c.tiles_x);
+                // rows: global pixel rows -> this partition's local rows (block-cyclic: about 1/n_parts of them)
+                double ly0 = (by - ry) / o.n_parts - o.row_block, ly1 = (by + ry) / o.n_parts + o.row_block;
+                c.hot_y0 = clampi(floor(ly0 / 8.0), 0, tiles_y);
+                c.hot_y1 = clampi(ceil(ly1 / 8.0), 0, tiles_y);
+                if (c.hot_x1 <= c.hot_x0 || c.hot_y1 <= c.hot_y0) c.hot_x0 = c.hot_x1 = c.hot_y0 = c.hot_y1 = 0;
+            }
+        }
     }
     int64_t n_q = (int64_t)c.tiles_x * tiles_y * 64;
     double lambda_max = fmax(5000.0, 6.0 * cam->r_obs); // metrics.py:1132

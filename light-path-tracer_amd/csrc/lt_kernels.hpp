@@ -31,7 +31,7 @@ struct CamConsts {
     int trace_rows;      // rows actually traced (tb_symmetry: (H+1)/2), n_parts == 1 only
     int use_tb;          // 1: rows >= H - H/2 copy row H-1-j (reference quirk Q1)
     int tiles_x, tiles_y;
-    int perm_c, perm_m;  // centre-out tile-row order: centre row, number of symmetric pairs
+    int hot_x0, hot_x1, hot_y0, hot_y1; // tile rectangle queued first (bounds the critical curve); may be empty
     int row_block, n_parts, part;
     int loop_around;
     double half_W, half_H, fx, fy; // x_cam = (ix - W/2) / fx  (image_lens.py:141-142)
@@ -52,40 +52,66 @@ __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
     return (b * c.n_parts + c.part) * c.row_block + o;
 }
 
-// Tile rows are queued centre-out from the row the black hole projects to (perm_c): position 0 is
-// row c, then c+1, c-1, c+2, ...; once one side is used up (perm_m pairs) the other continues.  The
-// rays that orbit near the critical curve -- up to ~50x the mean step count, a serial chain nothing
-// can shorten -- are therefore the first to start instead of forming the tail of the launch.
-__device__ __forceinline__ int queue_pos_to_tile_row(const CamConsts &c, int p)
+// Queue order of the tiles: first the rectangle [hot_x0, hot_x1) x [hot_y0, hot_y1) of tiles that
+// bounds the black hole's critical curve, row-major; then every other tile, row-major.  Rays that
+// orbit near the critical curve take up to ~50x the mean step count -- a serial chain nothing can
+// shorten -- so they must be the first to start, not the tail of the launch.  Both directions of
+// the map are closed-form (no table): K1 needs queue -> tile, K3 tile -> queue.
+__device__ __forceinline__ void queue_pos_to_tile(const CamConsts &c, int64_t pos, int &tx, int &ty)
 {
-    if (p <= 2 * c.perm_m) {
-        int kk = (p + 1) >> 1;
-        return (p & 1) ? c.perm_c + kk : c.perm_c - kk;
+    const int hw = c.hot_x1 - c.hot_x0, hh = c.hot_y1 - c.hot_y0;
+    const int64_t n_hot = (int64_t)hw * hh;
+    if (pos < n_hot) {
+        int rowi = (int)(pos / hw);
+        ty = c.hot_y0 + rowi;
+        tx = c.hot_x0 + (int)(pos - (int64_t)rowi * hw);
+        return;
     }
-    int rest = p - 2 * c.perm_m;
-    return (c.perm_c + c.perm_m + 1 < c.tiles_y) ? c.perm_c + c.perm_m + rest : c.perm_c - c.perm_m - rest;
+    int64_t p = pos - n_hot;
+    const int64_t top = (int64_t)c.hot_y0 * c.tiles_x;          // full rows above the rectangle
+    const int side = c.tiles_x - hw;                             // tiles per row beside the rectangle
+    const int64_t mid = (int64_t)hh * side;
+    if (p < top) {
+        ty = (int)(p / c.tiles_x);
+        tx = (int)(p - (int64_t)ty * c.tiles_x);
+    } else if (p < top + mid) {
+        p -= top;
+        int rowi = (int)(p / side), o = (int)(p - (int64_t)rowi * side);
+        ty = c.hot_y0 + rowi;
+        tx = o < c.hot_x0 ? o : o + hw;
+    } else {
+        p -= top + mid;
+        int rowi = (int)(p / c.tiles_x);
+        ty = c.hot_y1 + rowi;
+        tx = (int)(p - (int64_t)rowi * c.tiles_x);
+    }
 }
 
-__device__ __forceinline__ int tile_row_to_queue_pos(const CamConsts &c, int ty)
+__device__ __forceinline__ int64_t tile_to_queue_pos(const CamConsts &c, int tx, int ty)
 {
-    int d = ty - c.perm_c, ad = d < 0 ? -d : d;
-    if (ad <= c.perm_m) return d > 0 ? 2 * d - 1 : 2 * ad;
-    return 2 * c.perm_m + (ad - c.perm_m);
+    const int hw = c.hot_x1 - c.hot_x0, hh = c.hot_y1 - c.hot_y0;
+    const bool in_rows = ty >= c.hot_y0 && ty < c.hot_y1;
+    if (in_rows && tx >= c.hot_x0 && tx < c.hot_x1) return (int64_t)(ty - c.hot_y0) * hw + (tx - c.hot_x0);
+    const int64_t n_hot = (int64_t)hw * hh;
+    int64_t before; // hot tiles that precede (tx, ty) in plain row-major order
+    if (ty < c.hot_y0) before = 0;
+    else if (in_rows) before = (int64_t)(ty - c.hot_y0) * hw + (tx >= c.hot_x1 ? hw : 0);
+    else before = n_hot;
+    return n_hot + ((int64_t)ty * c.tiles_x + tx - before);
 }
 
 __device__ __forceinline__ void q_to_pixel(const CamConsts &c, int64_t q, int &ix, int &lrow)
 {
     int lane = (int)(q & 63);
-    int64_t tile = q >> 6;
-    int p = (int)(tile / c.tiles_x), tx = (int)(tile - (int64_t)p * c.tiles_x);
-    int ty = queue_pos_to_tile_row(c, p);
+    int tx, ty;
+    queue_pos_to_tile(c, q >> 6, tx, ty);
     ix = tx * 8 + (lane & 7);
     lrow = ty * 8 + (lane >> 3);
 }
 
 __device__ __forceinline__ int64_t pixel_to_q(const CamConsts &c, int ix, int lrow)
 {
-    int64_t tile = (int64_t)tile_row_to_queue_pos(c, lrow >> 3) * c.tiles_x + (ix >> 3);
+    int64_t tile = tile_to_queue_pos(c, ix >> 3, lrow >> 3);
     return (tile << 6) | ((lrow & 7) << 3) | (ix & 7);
 }
 
