@@ -33,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 import ltrace  # noqa: E402
+import sharding  # noqa: E402
 
 # As-written flop counts of the reference
 F_RK4_STEP = 4 * 188 + 80     # 832 per RK4 step   (metrics.py:221-323)
@@ -106,11 +107,11 @@ def main():
     met = ltrace.Metric(ltrace.METRIC_KERR if args.metric == "kerr" else ltrace.METRIC_SCHWARZSCHILD, 0, 1.0,
                         args.a if args.metric == "kerr" else 0.0)
     rb = args.row_block
-    rows = ltrace.local_rows(size, rb, world, rank)
     rows_max = max(ltrace.local_rows(size, rb, world, p) for p in range(world))
 
     # device buffers (torch owns the memory; the library only sees raw pointers)
-    d_rgba = torch.empty((rows_max, size, 4), dtype=torch.uint8, device=dev)
+    fg = sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank)   # RGBA8 framebuffer
+    d_rgba = fg.local
     d_fa = torch.empty((rows_max, size), dtype=torch.float32, device=dev)
     d_w = torch.empty((rows_max, size), dtype=torch.int16, device=dev)
     d_stats = torch.zeros(ltrace.STAT_WORDS, dtype=torch.int64, device=dev)
@@ -118,8 +119,6 @@ def main():
     if args.background:
         g = torch.Generator(device="cpu").manual_seed(0)
         d_bg = (torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8).to(torch.float32) / 255.0).to(dev)
-    full = torch.empty((size, size, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    gather_list = [torch.empty_like(d_rgba) for _ in range(world)] if (rank == 0 and world > 1) else None
 
     stream = torch.cuda.current_stream(dev)
     opts = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
@@ -130,13 +129,7 @@ def main():
         ltrace.render_dev(cam, met, opts, d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
                           d_fa=d_fa.data_ptr(), d_w=d_w.data_ptr(), d_rgba=d_rgba.data_ptr(),
                           d_stats=d_stats.data_ptr())
-        if world > 1:
-            dist.gather(d_rgba, gather_list, dst=0)
-            if rank == 0:
-                for p in range(world):
-                    ltrace.scatter_rows_dev(gather_list[p].data_ptr(), full.data_ptr(), size, size, 4, rb, world, p,
-                                            stream.cuda_stream)
-        # N = 1: the partition is the whole frame, already in row order in d_rgba
+        return fg.gather(stream.cuda_stream)   # N > 1: RCCL gather to rank 0 + row un-permute there
 
     def fence():
         if world > 1:

@@ -165,6 +165,21 @@ int lt_render(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts
               int8_t *out_status, uint32_t *out_steps, float *out_rgb, uint8_t *out_rgba,
               lt_stats *stats);
 
+/* ---- the first and the last stage on their own (HOST pointers) ------------------------------ *
+ * The reference's pipeline is three calls; lt_render fuses them, these keep each call a GPU twin. */
+
+/* Replaces build_alpha_lookup (image_lens.py:133-152) and the theta / axis-refine-column part of
+ * precompute_final_alpha_lookup_2d (image_lens.py:193-216).  Any output may be NULL:
+ * out_alpha (H, W) float32, out_theta (H, W) float64, out_axis_cols (W) bytes. */
+int lt_pixel_angles(const lt_camera *cam, double axis_refine_frac, float *out_alpha, double *out_theta,
+                    uint8_t *out_axis_cols);
+
+/* Replaces render_lensed_image (image_lens.py:296-397) for caller-supplied lookups (+ imsave's RGBA8):
+ * bg (H, W, bg_channels) float32, fa (H, W) float32, winding (H, W) uint16 or NULL;
+ * out_rgb (H, W, bg_channels) float32 and / or out_rgba (H, W, 4) uint8. */
+int lt_shade(const lt_camera *cam, int32_t loop_around, const float *bg, int32_t bg_channels, const float *fa,
+             const uint16_t *winding, float *out_rgb, uint8_t *out_rgba);
+
 /* Scatter a partition's (R, W, elem_bytes) rows into the full (H, W, elem_bytes) frame
  * (device pointers, async on `stream`): the un-permute step after the multi-GPU gather. */
 int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t height, int32_t width,

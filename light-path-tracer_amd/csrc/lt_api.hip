@@ -460,7 +460,8 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     { // "hot" tile rectangle, queued first: bounds the critical curve (largest impact parameter of a
       // spherical photon orbit: the retrograde equatorial one for Kerr, 3 sqrt(3) M for a = 0), + margin
         c.hot_x0 = c.hot_x1 = c.hot_y0 = c.hot_y1 = 0;
-        if (front) {
+        c.strip_x0 = c.strip_x1 = 0;
+        if (front && metric->kind == LT_METRIC_KERR) {
             double a = mc.a, M_ = mc.M;
             double b_max = 3.0 * sqrt(3.0) * M_;
             if (a != 0.0) { // Bardeen: r_ret = 2M (1 + cos(2/3 acos(|a|/M))), xi(r) as in metrics.py:886-887
@@ -485,6 +486,16 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
                 c.hot_y0 = clampi(floor(ly0 / 8.0), 0, tiles_y);
                 c.hot_y1 = clampi(ceil(ly1 / 8.0), 0, tiles_y);
                 if (c.hot_x1 <= c.hot_x0 || c.hot_y1 <= c.hot_y0) c.hot_x0 = c.hot_x1 = c.hot_y0 = c.hot_y1 = 0;
+                // spin-axis strip: +-16 px around the column the BH projects to; then move the rectangle's
+                // column range onto the grid with the strip removed
+                c.strip_x0 = clampi(floor((bx - 16.0) / 8.0), 0, c.tiles_x);
+                c.strip_x1 = clampi(ceil((bx + 16.0) / 8.0), 0, c.tiles_x);
+                if (c.strip_x1 < c.strip_x0) c.strip_x1 = c.strip_x0;
+                int sw = c.strip_x1 - c.strip_x0;
+                auto compact = [&](int x) { return x <= c.strip_x0 ? x : (x - sw > c.strip_x0 ? x - sw : c.strip_x0); };
+                c.hot_x0 = compact(c.hot_x0);
+                c.hot_x1 = compact(c.hot_x1);
+                if (c.hot_x1 <= c.hot_x0) c.hot_x0 = c.hot_x1 = c.hot_y0 = c.hot_y1 = 0;
             }
         }
     }
@@ -869,3 +880,5 @@ extern "C" int lt_piece_probe(int piece, int waves_per_simd, int iters, double *
     if (cycles_per_eval) *cycles_per_eval = (double)ms * 1e-3 * mhz * 1e6 / ((double)iters * 4.0 * waves_per_simd);
     return LT_OK;
 }
+
+#include "lt_api_stages.inc"

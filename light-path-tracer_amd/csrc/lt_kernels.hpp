@@ -31,7 +31,9 @@ struct CamConsts {
     int trace_rows;      // rows actually traced (tb_symmetry: (H+1)/2), n_parts == 1 only
     int use_tb;          // 1: rows >= H - H/2 copy row H-1-j (reference quirk Q1)
     int tiles_x, tiles_y;
-    int hot_x0, hot_x1, hot_y0, hot_y1; // tile rectangle queued first (bounds the critical curve); may be empty
+    int strip_x0, strip_x1;             // tile columns queued first (spin-axis rays); may be empty
+    int hot_x0, hot_x1, hot_y0, hot_y1; // tile rectangle queued next (bounds the critical curve), in columns
+                                        // compacted by the strip; may be empty
     int row_block, n_parts, part;
     int loop_around;
     double half_W, half_H, fx, fy; // x_cam = (ix - W/2) / fx  (image_lens.py:141-142)
@@ -52,52 +54,72 @@ __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
     return (b * c.n_parts + c.part) * c.row_block + o;
 }
 
-// Queue order of the tiles: first the rectangle [hot_x0, hot_x1) x [hot_y0, hot_y1) of tiles that
-// bounds the black hole's critical curve, row-major; then every other tile, row-major.  Rays that
-// orbit near the critical curve take up to ~50x the mean step count -- a serial chain nothing can
-// shorten -- so they must be the first to start, not the tail of the launch.  Both directions of
-// the map are closed-form (no table): K1 needs queue -> tile, K3 tile -> queue.
+// Queue order of the tiles, so that the slowest rays START FIRST instead of forming the tail of the
+// launch (a ray is a serial chain nothing can shorten, and the slowest take ~50x the mean):
+//   1. the strip of tile columns [strip_x0, strip_x1) the spin axis projects to, every row -- rays
+//      that pass over the pole (axis-refine rays with L ~ 0) hold the step-count records, at any row;
+//   2. the rectangle of tiles bounding the critical curve -- rays that orbit near it;
+//   3. everything else, row-major.
+// Parts 2 and 3 live on the grid with the strip's columns removed (width cw = tiles_x - strip width;
+// hot_x0 / hot_x1 are in those compacted columns).  Both directions of the map are closed-form (no
+// table): K1 needs queue -> tile, K3 tile -> queue.
 __device__ __forceinline__ void queue_pos_to_tile(const CamConsts &c, int64_t pos, int &tx, int &ty)
 {
+    const int sw = c.strip_x1 - c.strip_x0;
+    const int64_t n_strip = (int64_t)sw * c.tiles_y;
+    if (pos < n_strip) {
+        ty = (int)(pos / sw);
+        tx = c.strip_x0 + (int)(pos - (int64_t)ty * sw);
+        return;
+    }
+    pos -= n_strip;
+    const int cw = c.tiles_x - sw;
     const int hw = c.hot_x1 - c.hot_x0, hh = c.hot_y1 - c.hot_y0;
     const int64_t n_hot = (int64_t)hw * hh;
+    int cx;
     if (pos < n_hot) {
         int rowi = (int)(pos / hw);
         ty = c.hot_y0 + rowi;
-        tx = c.hot_x0 + (int)(pos - (int64_t)rowi * hw);
-        return;
-    }
-    int64_t p = pos - n_hot;
-    const int64_t top = (int64_t)c.hot_y0 * c.tiles_x;          // full rows above the rectangle
-    const int side = c.tiles_x - hw;                             // tiles per row beside the rectangle
-    const int64_t mid = (int64_t)hh * side;
-    if (p < top) {
-        ty = (int)(p / c.tiles_x);
-        tx = (int)(p - (int64_t)ty * c.tiles_x);
-    } else if (p < top + mid) {
-        p -= top;
-        int rowi = (int)(p / side), o = (int)(p - (int64_t)rowi * side);
-        ty = c.hot_y0 + rowi;
-        tx = o < c.hot_x0 ? o : o + hw;
+        cx = c.hot_x0 + (int)(pos - (int64_t)rowi * hw);
     } else {
-        p -= top + mid;
-        int rowi = (int)(p / c.tiles_x);
-        ty = c.hot_y1 + rowi;
-        tx = (int)(p - (int64_t)rowi * c.tiles_x);
+        int64_t p = pos - n_hot;
+        const int64_t top = (int64_t)c.hot_y0 * cw; // full rows above the rectangle
+        const int side = cw - hw;                    // tiles per row beside the rectangle
+        const int64_t mid = (int64_t)hh * side;
+        if (p < top) {
+            ty = (int)(p / cw);
+            cx = (int)(p - (int64_t)ty * cw);
+        } else if (p < top + mid) {
+            p -= top;
+            int rowi = (int)(p / side), o = (int)(p - (int64_t)rowi * side);
+            ty = c.hot_y0 + rowi;
+            cx = o < c.hot_x0 ? o : o + hw;
+        } else {
+            p -= top + mid;
+            int rowi = (int)(p / cw);
+            ty = c.hot_y1 + rowi;
+            cx = (int)(p - (int64_t)rowi * cw);
+        }
     }
+    tx = cx < c.strip_x0 ? cx : cx + sw;
 }
 
 __device__ __forceinline__ int64_t tile_to_queue_pos(const CamConsts &c, int tx, int ty)
 {
+    const int sw = c.strip_x1 - c.strip_x0;
+    if (tx >= c.strip_x0 && tx < c.strip_x1) return (int64_t)ty * sw + (tx - c.strip_x0);
+    const int64_t n_strip = (int64_t)sw * c.tiles_y;
+    const int cw = c.tiles_x - sw;
+    const int cx = tx < c.strip_x0 ? tx : tx - sw;
     const int hw = c.hot_x1 - c.hot_x0, hh = c.hot_y1 - c.hot_y0;
     const bool in_rows = ty >= c.hot_y0 && ty < c.hot_y1;
-    if (in_rows && tx >= c.hot_x0 && tx < c.hot_x1) return (int64_t)(ty - c.hot_y0) * hw + (tx - c.hot_x0);
+    if (in_rows && cx >= c.hot_x0 && cx < c.hot_x1) return n_strip + (int64_t)(ty - c.hot_y0) * hw + (cx - c.hot_x0);
     const int64_t n_hot = (int64_t)hw * hh;
-    int64_t before; // hot tiles that precede (tx, ty) in plain row-major order
+    int64_t before; // hot tiles that precede (cx, ty) in plain row-major order of the compacted grid
     if (ty < c.hot_y0) before = 0;
-    else if (in_rows) before = (int64_t)(ty - c.hot_y0) * hw + (tx >= c.hot_x1 ? hw : 0);
+    else if (in_rows) before = (int64_t)(ty - c.hot_y0) * hw + (cx >= c.hot_x1 ? hw : 0);
     else before = n_hot;
-    return n_hot + ((int64_t)ty * c.tiles_x + tx - before);
+    return n_strip + n_hot + ((int64_t)ty * cw + cx - before);
 }
 
 __device__ __forceinline__ void q_to_pixel(const CamConsts &c, int64_t q, int &ix, int &lrow)

@@ -81,6 +81,9 @@ SIGNATURES = {
     "lt_scatter_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p]),
     "lt_timing_collect": (C.c_int, [_dp, _dp, _dp, C.POINTER(C.c_int32)]),
+    "lt_pixel_angles": (C.c_int, [C.POINTER(Camera), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_shade": (C.c_int, [C.POINTER(Camera), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                           C.c_void_p, C.c_void_p]),
     "lt_valu_peak_probe": (C.c_int, [C.c_int, C.c_int, _dp]),
     "lt_valu_issue_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _dp, _dp]),
     "lt_valu_issue_probe_count": (C.c_int, []),
@@ -238,6 +241,34 @@ def render(cam, metric, opts, background=None, want=("fa", "winding", "status", 
                             C.byref(st)))
     out["stats"] = stats_dict(st.counters, st.prologue_ms, st.integrate_ms, st.epilogue_ms)
     return out
+
+
+def pixel_angles(cam, axis_refine_frac=0.07, want_theta=True):
+    """(alpha (H,W) f32, theta (H,W) f64 or None, axis_refine_cols (W,) bool) -- lt_pixel_angles."""
+    H, W = cam.height, cam.width
+    alpha = np.empty((H, W), dtype=np.float32)
+    theta = np.empty((H, W), dtype=np.float64) if want_theta else None
+    cols = np.zeros(W, dtype=np.uint8)
+    _check(load().lt_pixel_angles(C.byref(cam), axis_refine_frac, _np_ptr(alpha), _np_ptr(theta), _np_ptr(cols)))
+    return alpha, theta, cols.astype(bool)
+
+
+def shade(cam, background, fa, winding=None, loop_around=False, want_rgba=False):
+    """render_lensed_image twin (lt_shade): returns rgb like the background (and rgba8 if asked)."""
+    bg = np.ascontiguousarray(background, dtype=np.float32)
+    H, W = bg.shape[:2]
+    if (H, W) != (cam.height, cam.width):
+        raise ValueError("background and camera sizes differ")
+    nch = 1 if bg.ndim == 2 else bg.shape[2]
+    fa32 = np.ascontiguousarray(fa, dtype=np.float32)
+    wd = None if winding is None else np.ascontiguousarray(winding, dtype=np.uint16)
+    if fa32.shape != (H, W) or (wd is not None and wd.shape != (H, W)):
+        raise ValueError("lookup shapes must be (H, W)")
+    rgb = np.empty_like(bg)
+    rgba = np.empty((H, W, 4), dtype=np.uint8) if want_rgba else None
+    _check(load().lt_shade(C.byref(cam), int(bool(loop_around)), _np_ptr(bg), nch, _np_ptr(fa32), _np_ptr(wd),
+                           _np_ptr(rgb), _np_ptr(rgba)))
+    return (rgb, rgba) if want_rgba else rgb
 
 
 def stats_dict(counters, prologue_ms=0.0, integrate_ms=0.0, epilogue_ms=0.0):

@@ -1,0 +1,82 @@
+"""Row sharding of a frame across the GPUs of one node, one process per GPU.
+
+The frame tiles trivially: pixels are independent, so ranks share no data while rendering and the
+only exchange is the gather of the finished framebuffer to rank 0 (RCCL over xGMI when the process
+group's backend is "nccl"; the same code runs on "gloo" for the CPU tests).
+
+Partition: block-cyclic rows -- block b of `row_block` rows belongs to rank b % world.  Row cost is
+far from uniform (shadow rows are cheap, critical-curve rows expensive), so contiguous slabs would
+leave most GPUs idle; small cyclic blocks give every rank the same mix.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import ltrace
+
+
+def local_rows(height, row_block, world, rank):
+    """Number of rows rank `rank` owns."""
+    return ltrace.local_rows(height, row_block, world, rank)
+
+
+def global_row_index(height, row_block, world, rank):
+    """int64 tensor: global row of every local row of `rank` (ascending)."""
+    return torch.from_numpy(ltrace.global_rows(height, row_block, world, rank))
+
+
+class FrameGather:
+    """Gathers per-rank row partitions (R_rank, W, C) of one dtype to the full (H, W, C) frame on rank 0.
+
+    Buffers are allocated once; `gather(local)` is collective.  Partitions are padded to the largest
+    partition so a plain dist.gather (ncclGather-style send/recv into rank 0) suffices."""
+
+    def __init__(self, height, width, channels, dtype, device, row_block, world=None, rank=None):
+        self.world = dist.get_world_size() if world is None else world
+        self.rank = dist.get_rank() if rank is None else rank
+        self.h, self.w, self.c = height, width, channels
+        self.row_block = row_block
+        self.device = torch.device(device)
+        self.rows = [local_rows(height, row_block, self.world, r) for r in range(self.world)]
+        self.rows_max = max(self.rows)
+        self.local = torch.empty((self.rows_max, width, channels), dtype=dtype, device=self.device)
+        self.full = None
+        self.parts = None
+        if self.rank == 0:
+            self.full = torch.empty((height, width, channels), dtype=dtype, device=self.device)
+            if self.world > 1:
+                self.parts = [torch.empty_like(self.local) for _ in range(self.world)]
+        self._index = None
+
+    def local_view(self):
+        """(R_rank, W, C) view this rank renders into."""
+        return self.local[: self.rows[self.rank]]
+
+    def gather(self, stream_ptr=0):
+        """Collective.  Rank 0 returns the assembled (H, W, C) frame, other ranks None."""
+        if self.world == 1:
+            # one partition = the whole frame, already in row order
+            return self.local[: self.h]
+        dist.gather(self.local, self.parts, dst=0)
+        if self.rank != 0:
+            return None
+        elem = self.local.element_size() * self.c
+        for r in range(self.world):
+            if self.rows[r] == 0:
+                continue
+            if self.device.type == "cuda":
+                ltrace.scatter_rows_dev(self.parts[r].data_ptr(), self.full.data_ptr(), self.h, self.w, elem,
+                                        self.row_block, self.world, r, stream_ptr)
+            else:
+                if self._index is None:
+                    self._index = [global_row_index(self.h, self.row_block, self.world, q) for q in range(self.world)]
+                self.full[self._index[r]] = self.parts[r][: self.rows[r]]
+        return self.full
+
+
+def reference_partition_check(height, row_block, world):
+    """All ranks' rows form a partition of range(height) (host-only helper for tests)."""
+    seen = np.zeros(height, dtype=np.int64)
+    for r in range(world):
+        seen[ltrace.global_rows(height, row_block, world, r)] += 1
+    return bool(np.all(seen == 1))

@@ -1,0 +1,135 @@
+"""GPU tests of the image pipeline surface (image_lens.py / black_hole_shadow.py of the product):
+each reference stage has a GPU twin, the twins agree with the reference's golden outputs, and the
+fused path equals the staged path bit for bit."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import black_hole_shadow
+import image_lens
+import ltrace
+import metrics
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+LOOKUPS = ["4x6_a0", "4x6_a0p9", "48x64_a0", "48x64_a0p9", "48x64_a0_psi", "48x64_a0p9_psi", "33x40_a0p9"]
+
+
+def _g(name):
+    g = np.load(os.path.join(GOLD, f"lookup_{name}.npz"))
+    return g, json.loads(str(g["meta"]))
+
+
+@pytest.mark.parametrize("name", LOOKUPS)
+def test_stage1_alpha_lookup_is_bit_exact(name):
+    """build_alpha_lookup (reference image_lens.py:133-152): float32, bit for bit; theta to 1e-12."""
+    g, m = _g(name)
+    fov, psi = (m["hfov"], m["vfov"]), tuple(m["psi"])
+    al = image_lens.build_alpha_lookup((m["h"], m["w"]), fov, psi=psi)
+    assert al.dtype == np.float32
+    np.testing.assert_array_equal(al, g["alpha_lookup"])
+    cam = ltrace.Camera(m["w"], m["h"], fov[0], fov[1], psi[0], psi[1], 50.0, np.pi / 2)
+    _, th, cols = ltrace.pixel_angles(cam)
+    _, th_o, cols_o = oracle.pixel_angles(m["h"], m["w"], fov[0], fov[1], psi=psi)
+    far = al > 1e-6
+    assert np.max(np.abs(th[far] - th_o[far])) < 1e-12
+    np.testing.assert_array_equal(cols, cols_o)
+
+
+@pytest.mark.parametrize("name", LOOKUPS)
+def test_stage3_render_matches_reference_bit_for_bit(name):
+    """render_lensed_image (reference image_lens.py:296-397) fed with the REFERENCE's lookups."""
+    g, m = _g(name)
+    fov, psi = (m["hfov"], m["vfov"]), tuple(m["psi"])
+    al = g["alpha_lookup"]
+    img = image_lens.render_lensed_image(g["background"], al, g["final_alpha"], g["winding"], m["alpha_crit"], fov, psi=psi)
+    np.testing.assert_array_equal(img, g["lensed"])
+    wrap = image_lens.render_lensed_image(g["background"], al, g["final_alpha"], g["winding"], m["alpha_crit"], fov,
+                                          render_loop_around=True, psi=psi)
+    np.testing.assert_array_equal(wrap, g["lensed_wrap"])
+    gray = image_lens.render_lensed_image(g["background"][..., 1].copy(), al, g["final_alpha"], g["winding"],
+                                          m["alpha_crit"], fov, psi=psi)
+    np.testing.assert_array_equal(gray, g["lensed_gray"])
+    # winding lookup omitted -> colour index 0 (image_lens.py:326-327)
+    none_w = image_lens.render_lensed_image(g["background"], al, g["final_alpha"], None, m["alpha_crit"], fov, psi=psi)
+    exp = oracle.render(g["background"], g["final_alpha"], None, fov[0], fov[1], psi=psi)
+    np.testing.assert_array_equal(none_w, exp)
+
+
+@pytest.mark.parametrize("name", ["48x64_a0", "48x64_a0_psi", "4x6_a0"])
+def test_stage2_schwarzschild_lookup_matches_reference(name):
+    """precompute_final_alpha_lookup (reference image_lens.py:155-178), float64 and float32 kernels."""
+    g, m = _g(name)
+    for precision, tol in ((64, 1e-6), (32, 2e-4)):
+        S = metrics.Schwarzschild(1.0, precision=precision)
+        fa, wd, total, traced = image_lens.precompute_final_alpha_lookup(g["alpha_lookup"], m["alpha_crit"], m["r_obs"], S)
+        assert (total, traced) == (m["total"], m["traced"]) and fa.dtype == np.float32 and wd.dtype == np.uint16
+        assert np.array_equal(np.isnan(fa), np.isnan(g["final_alpha"]))
+        assert np.nanmax(np.abs(fa - g["final_alpha"])) <= tol
+        assert (wd != g["winding"]).sum() == 0
+
+
+def test_stage2_kerr_lookup_reproduces_tb_mirror_quirk():
+    """precompute_final_alpha_lookup_2d (reference image_lens.py:185-280) incl. quirk Q1, against the
+    oracle running the same integrator (RK4, float64) on an odd-height frame."""
+    g, m = _g("33x40_a0p9")
+    fov = (m["hfov"], m["vfov"])
+    K = metrics.Kerr(1.0, 0.9, integrator="rk4", precision=64)
+    fa, wd, total, traced = image_lens.precompute_final_alpha_lookup_2d(g["alpha_lookup"], fov, m["alpha_crit"], m["r_obs"], K)
+    assert (total, traced) == (m["total"], m["traced"]) == (33 * 40, 17 * 40)
+    ref = oracle.lookup("kerr", 1.0, 0.9, m["r_obs"], 33, 40, fov[0], fov[1], integrator="rk4", tb_symmetry=True)
+    assert np.array_equal(np.isnan(fa), np.isnan(ref["fa"]))
+    assert np.nanmax(np.abs(fa - ref["fa"])) < 1e-6
+    np.testing.assert_array_equal(wd, ref["winding"])
+    np.testing.assert_array_equal(fa[33 - 16:], fa[:16][::-1])          # row j copied to row H-1-j
+    # psi_y != 0 switches the mirror off (image_lens.py:218-219)
+    fa2, _, _, traced2 = image_lens.precompute_final_alpha_lookup_2d(g["alpha_lookup"], fov, m["alpha_crit"], m["r_obs"], K,
+                                                                     psi=(0.1, 0.0))
+    assert traced2 == 33 * 40
+
+
+@pytest.mark.parametrize("a", [0.0, 0.9])
+def test_fused_path_equals_staged_path(a):
+    """lt_render == build_alpha_lookup -> trace_rays_batch -> render_lensed_image, bit for bit."""
+    H, W = 120, 168
+    vfov = np.radians(40.0)
+    fov = (2 * np.arctan(np.tan(vfov / 2) * W / H), vfov)
+    psi = (0.03, -0.04)
+    bg = image_lens.synthetic_background(H, W, 7)
+    metric = metrics.Schwarzschild(1.0) if a == 0 else metrics.Kerr(1.0, a, integrator="rk4", precision=32)
+    al = image_lens.build_alpha_lookup((H, W), fov, psi=psi)
+    if a == 0:
+        fa, wd, _, _ = image_lens.precompute_final_alpha_lookup(al, 0.0, 100.0, metric)
+    else:
+        fa, wd, _, _ = image_lens.precompute_final_alpha_lookup_2d(al, fov, 0.0, 100.0, metric, psi=psi)
+    staged = image_lens.render_lensed_image(bg, al, fa, wd, 0.0, fov, psi=psi)
+    fused = image_lens.render_frame(bg, metric, 100.0, fov, psi=psi)
+    assert np.array_equal(fused["fa"], fa, equal_nan=True)
+    np.testing.assert_array_equal(fused["winding"], wd)
+    np.testing.assert_array_equal(fused["rgb"], staged)
+
+
+def test_cli_main_runs_end_to_end(tmp_path, capsys):
+    out = tmp_path / "lensed.png"
+    img = image_lens.main(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), output_path=str(out))
+    text = capsys.readouterr().out
+    assert img.shape == (64, 96, 3) and out.exists()
+    assert "Metric: Kerr (M=1.0, a=0.9)" in text and "Benchmark summary" in text and "total rays: 6,144" in text
+    staged = image_lens.main(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), output_path=str(out), staged=True)
+    # staged mode applies the reference's top/bottom mirror, the fused default does not: compare the top half
+    np.testing.assert_array_equal(staged[:32], img[:32])
+
+
+def test_traced_shadow_matches_oracle():
+    S = metrics.Schwarzschild(1.0)
+    img, status, stats = black_hole_shadow.render_traced(S, 256, 256)
+    al, _, _ = oracle.pixel_angles(256, 256, np.radians(40.0), np.radians(40.0))
+    assert ((img == 0) != (al.astype(np.float64) < S.alpha_crit(50.0))).sum() <= 4
+    assert stats["rays"] == 256 * 256
+    K = metrics.Kerr(1.0, 0.9)
+    imgk, statusk, _ = black_hole_shadow.render_traced(K, 128, 128)
+    ref = oracle.lookup("kerr", 1.0, 0.9, 50.0, 128, 128, np.radians(40.0), np.radians(40.0), integrator="rk4")
+    assert ((statusk == 1) != (ref["status"] == 1)).sum() <= 16

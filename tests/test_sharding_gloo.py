@@ -1,0 +1,71 @@
+"""The multi-GPU path (row partition + gather to rank 0 + un-permute) on CPU with two processes over
+gloo: same sharding.FrameGather the benchmark uses with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ltrace
+import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _pixel_value(rows, width, channels):
+    """A frame whose content encodes (global row, column, channel): any misplaced row shows."""
+    r = rows.to(torch.int64)[:, None, None]
+    x = torch.arange(width)[None, :, None]
+    ch = torch.arange(channels)[None, None, :]
+    return ((r * 131 + x * 7 + ch * 3) % 251).to(torch.uint8)
+
+
+def _worker(rank, world, port, height, width, row_block, out_path):
+    for p in (ROOT, os.path.join(ROOT, "light-path-tracer_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fg = sharding.FrameGather(height, width, 4, torch.uint8, "cpu", row_block, world, rank)
+        rows = sharding.global_row_index(height, row_block, world, rank)
+        assert fg.local_view().shape[0] == rows.numel()
+        fg.local_view().copy_(_pixel_value(rows, width, 4))      # "render" this rank's rows
+        for _ in range(2):                                        # buffers are reusable across frames
+            full = fg.gather()
+        if rank == 0:
+            expect = _pixel_value(torch.arange(height), width, 4)
+            assert torch.equal(full, expect)
+            np.save(out_path, np.array([1]))
+        else:
+            assert full is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("height,width,row_block", [(64, 40, 16), (37, 9, 8), (5, 3, 16)])
+def test_two_rank_gather_reassembles_the_frame(tmp_path, height, width, row_block):
+    world = 2
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(world, _free_port(), height, width, row_block, out), nprocs=world, join=True)
+    assert os.path.exists(out)
+
+
+def test_partition_covers_every_row_once():
+    for h, rb, w in [(4096, 16, 8), (8192, 16, 8), (33, 16, 2), (100, 7, 3), (5, 16, 8)]:
+        assert sharding.reference_partition_check(h, rb, w)
+        assert sum(sharding.local_rows(h, rb, w, r) for r in range(w)) == h
+    # the benchmark frame splits evenly at 1, 2, 4, 8 ranks
+    for w in (1, 2, 4, 8):
+        assert {ltrace.local_rows(4096, 16, w, r) for r in range(w)} == {4096 // w}
