@@ -170,6 +170,17 @@ def main():
     value = rays_per_frame / (elapsed / steps) / 1e6
 
     if rank == 0:
+        # HBM bytes per launch of the integrate kernel: PMC counters cannot be read from inside this
+        # process, so the figure comes from the committed rocprofv3 pass for this exact workload
+        workload = f"{args.metric}_a{args.a}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                rec = json.load(f).get(workload)
+            if rec and world == 1 and args.precision == 32 and not args.background:
+                traffic = rec.get(args.schedule)
+        except OSError:
+            pass
         integ_ms = float(kern_max[1].item()) / steps          # slowest rank's average integrate-kernel time
         achieved = (flops_frame / world) / (integ_ms * 1e-3) / 1e12 if integ_ms > 0 else 0.0
         out = {
@@ -186,7 +197,7 @@ def main():
                        "invalid": c[ltrace.STAT_INVALID] // steps},
             "roofline": {"bound": "valu_fp32", "kernel": "k_kerr_rk4_" + args.schedule if args.metric == "kerr" else "k_schw_rk4_direct",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_flops_per_launch": int(flops_frame / world),
                          "avg_launch_ms": round(integ_ms, 4),
                          "other_kernels_ms": {"prologue": round(float(kern_max[0].item()) / steps, 4),
