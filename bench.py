@@ -195,7 +195,7 @@ def main():
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
                        "invalid": c[ltrace.STAT_INVALID] // steps},
-            "roofline": {"bound": "valu_fp32", "kernel": "k_kerr_rk4_" + args.schedule if args.metric == "kerr" else "k_schw_rk4_direct",
+            "roofline": {"bound": "valu_fp32", "kernel": f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
                          "algorithmic_flops_per_launch": int(flops_frame / world),

@@ -241,6 +241,8 @@ static int make_metric(const lt_metric *m, double r_obs, double theta_obs, doubl
     mc->r_capture = mc->r_plus * 1.01;                        // metrics.py:428, :579
     mc->R_S = 2.0 * mc->M;                                    // metrics.py:742
     mc->phi_h = h_schw;
+    mc->evals_fixed = 0;
+    mc->evals_per_step = 4;
     return LT_OK;
 }
 
@@ -367,14 +369,16 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
         k_schw_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q);
     } else {
         KerrConsts<T> k = make_kerr<T>(mc, lambda_max, o.h_max);
-        if (o.integrator != LT_INTEGRATOR_RK4) return fail(LT_ERR_UNSUPPORTED, "DP45 integrator not built yet");
+        const bool dp45 = o.integrator == LT_INTEGRATOR_DP45;
+        if (dp45 && sizeof(T) != 8) return fail(LT_ERR_UNSUPPORTED, "DP45 needs precision 64");
         StampDump sd;
         if (o.schedule == LT_SCHED_DIRECT) {
             static const int k2_block = [] { int b = env_int("LT_K2_BLOCK", 64);
                                              return (b == 64 || b == 128 || b == 256) ? b : 64; }();
             unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
             if ((rc = sd.begin((size_t)(n_q / 64)))) return rc;
-            k_kerr_rk4_direct<T><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, sd.dev);
+            if constexpr (sizeof(T) == 8) { if (dp45) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, sd.dev); }
+            if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, sd.dev);
         } else {
             if (n_q >= (int64_t)1 << 32) return fail(LT_ERR_UNSUPPORTED, "queue schedule: more than 2^32 rays");
             int cus;
@@ -388,8 +392,15 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             if (qgrid > grid) qgrid = grid;
             HIP_TRY(hipMemsetAsync(w.head, 0, sizeof(uint32_t), s));
             if ((rc = sd.begin((size_t)qgrid * 4))) return rc;
-            k_kerr_rk4_queue<T><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint32_t)n_q, w.head,
-                                                      (uint32_t)chunk, (uint32_t)refill_min, (uint32_t)long_steps, sd.dev);
+            if constexpr (sizeof(T) == 8) {
+                if (dp45) // "long" is measured in step attempts: DP45 rays take ~50, not ~150
+                    k_kerr_queue<T, Dp45<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint32_t)n_q,
+                                                                 w.head, (uint32_t)chunk, (uint32_t)refill_min,
+                                                                 (uint32_t)(long_steps / 3), sd.dev);
+            }
+            if (!dp45)
+                k_kerr_queue<T, Rk4<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint32_t)n_q, w.head,
+                                                            (uint32_t)chunk, (uint32_t)refill_min, (uint32_t)long_steps, sd.dev);
         }
         HIP_TRY(hipGetLastError());
         if ((rc = sd.end())) return rc;
@@ -429,6 +440,7 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     if ((rc = check_opts(metric, &o))) return rc;
     MetricConsts mc;
     if ((rc = make_metric(metric, cam->r_obs, cam->theta_obs, o.h_max, &mc))) return rc;
+    if (metric->kind == LT_METRIC_KERR && o.integrator == LT_INTEGRATOR_DP45) { mc.evals_fixed = 1; mc.evals_per_step = 6; }
 
     CamConsts c;
     memset(&c, 0, sizeof(c));
@@ -676,6 +688,7 @@ extern "C" int lt_trace_batch_kerr(double M, double a, double r_obs, const doubl
     if ((rc = check_opts(&m, &o))) return rc;
     MetricConsts mc;
     if ((rc = make_metric(&m, r_obs, theta_obs, 0.0, &mc))) return rc;
+    if (integrator == LT_INTEGRATOR_DP45) { mc.evals_fixed = 1; mc.evals_per_step = 6; }
     return trace_batch(mc, o, lambda_max, alphas, thetas, axis_refines, n, out_fa, out_w, out_status, out_rhs_evals);
 }
 

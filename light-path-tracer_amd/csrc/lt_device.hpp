@@ -86,6 +86,44 @@ template <> struct M<float> {
     static __device__ __forceinline__ bool finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 };
 
+// sin and cos of a float64 angle of modest size without libm's generic range reduction: Cody-Waite
+// by pi/2 (fdlibm's pio2_1 + pio2_1t split, a double-double remainder y0 + y1 good to |x| ~ 1e5) and
+// the fdlibm kernel polynomials on [-pi/4, pi/4] (< 1 ulp).  ~40 float64 FMA-class instructions, no
+// branches, no scratch -- OCML's sincos carries a Payne-Hanek path and costs registers and time.
+__device__ __forceinline__ void sincos_f64(double x, double &s, double &c)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632673412561417e+00, P1T = 6.07710050650619224932e-11;
+    double kf = __builtin_rint(x * TWO_OVER_PI);
+    double r = __builtin_fma(-kf, P1, x);
+    double w = kf * P1T;
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+    int k = (int)kf;
+    double z = y0 * y0;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = __builtin_fma(z, S6, S5);
+    ps = __builtin_fma(z, ps, S4);
+    ps = __builtin_fma(z, ps, S3);
+    ps = __builtin_fma(z, ps, S2);
+    ps = __builtin_fma(z, ps, S1);
+    double sy = __builtin_fma(z * y0, ps, y0);
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = __builtin_fma(z, C6, C5);
+    pc = __builtin_fma(z, pc, C4);
+    pc = __builtin_fma(z, pc, C3);
+    pc = __builtin_fma(z, pc, C2);
+    pc = __builtin_fma(z, pc, C1);
+    double cy = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    double sr = __builtin_fma(y1, cy, sy), cr = __builtin_fma(-y1, sy, cy); // first-order in the low word
+    bool swap = k & 1;
+    double ss = swap ? cr : sr, cc = swap ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
+}
+
 template <> struct M<double> {
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
     static __device__ __forceinline__ double rcp_pos(double x) { return 1.0 / x; }
@@ -94,7 +132,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
     static __device__ __forceinline__ double sin2_floor(double s) { return __builtin_fmax(s * s, 1e-15); }
-    static __device__ __forceinline__ void sincos(double x, double &s, double &c) { ::sincos(x, &s, &c); }
+    static __device__ __forceinline__ void sincos(double x, double &s, double &c) { sincos_f64(x, s, c); }
     static __device__ __forceinline__ bool finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 };
 

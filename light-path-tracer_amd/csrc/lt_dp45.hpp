@@ -1,0 +1,140 @@
+// lt_dp45.hpp -- the reference's production Kerr integrator: adaptive Dormand-Prince 4(5) with FSAL
+// (metrics.py:419-567), one step ATTEMPT per call so that both schedules of the integrate kernel
+// can drive it.  Float64 only: the reference tolerances (rtol 1e-6 / 1e-8 on axis-refine rays) are at
+// or below float32 resolution (in float32 the step controller thrashes).
+//
+// Also the integrator "policies" the integrate kernels are templated on (Rk4<T>, Dp45<T>).
+#pragma once
+#include "lt_device.hpp"
+
+namespace lt {
+
+// ---------------------------------------------------------------------------------------------
+// fixed-step RK4 as an integrator policy
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Rk4 {
+    using State = RayState<T>;
+    static constexpr int EVALS_FIXED = 0, EVALS_PER_STEP = 4;
+    static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &, State &s, T p_r, T p_th)
+    {
+        ray_start(k, s, p_r, p_th);
+    }
+    static __device__ __forceinline__ int advance(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s)
+    {
+        return kerr_rk4_advance(k, rc, s);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Dormand-Prince 4(5)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Dp45State {
+    State5<T> y;
+    T k1[5];       // FSAL: derivative at y
+    T lam, h;
+    uint32_t steps; // step attempts (accepted + rejected), metrics.py:454
+};
+
+template <typename T> struct Dp45 {
+    using State = Dp45State<T>;
+    static constexpr int EVALS_FIXED = 1, EVALS_PER_STEP = 6;
+
+    static __device__ __forceinline__ void rhs5(const KerrConsts<T> &k, const RayConsts<T> &rc, const T *y, T *d)
+    {
+        kerr_rhs(k, rc, y[0], y[1], y[3], y[4], d[0], d[1], d[2], d[3], d[4]);
+    }
+
+    static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, T p_r, T p_th)
+    {
+        s.y.r = k.r_obs; s.y.th = k.theta_obs; s.y.ph = T(0); s.y.pr = p_r; s.y.pth = p_th;
+        T y[5] = {s.y.r, s.y.th, s.y.ph, s.y.pr, s.y.pth};
+        rhs5(k, rc, y, s.k1);                               // metrics.py:446
+        s.lam = T(0);
+        s.h = M<T>::max(T(1), T(0.01) * k.r_obs);           // metrics.py:449
+        s.steps = 0;
+    }
+
+    // One attempt of the loop body metrics.py:454-564.
+    static __device__ __forceinline__ int advance(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s)
+    {
+        const T A21 = T(1.0 / 5.0), A31 = T(3.0 / 40.0), A32 = T(9.0 / 40.0), A41 = T(44.0 / 45.0), A42 = T(-56.0 / 15.0),
+                A43 = T(32.0 / 9.0), A51 = T(19372.0 / 6561.0), A52 = T(-25360.0 / 2187.0), A53 = T(64448.0 / 6561.0),
+                A54 = T(-212.0 / 729.0), A61 = T(9017.0 / 3168.0), A62 = T(-355.0 / 33.0), A63 = T(46732.0 / 5247.0),
+                A64 = T(49.0 / 176.0), A65 = T(-5103.0 / 18656.0);
+        const T B1 = T(35.0 / 384.0), B3 = T(500.0 / 1113.0), B4 = T(125.0 / 192.0), B5 = T(-2187.0 / 6784.0), B6 = T(11.0 / 84.0);
+        const T E1 = T(71.0 / 57600.0), E3 = T(-71.0 / 16695.0), E4 = T(71.0 / 1920.0), E5 = T(-17253.0 / 339200.0),
+                E6 = T(22.0 / 525.0), E7 = T(-1.0 / 40.0);
+        const T h_min = T(1e-12);
+        if (s.steps >= 200000u || !(s.lam < k.lambda_max)) return EV_MAXRANGE;
+        T remaining = k.lambda_max - s.lam;
+        if (s.h > remaining) s.h = remaining;
+        if (!(s.h > T(0))) return EV_MAXRANGE;
+        ++s.steps;
+        const T h = s.h;
+        const T y[5] = {s.y.r, s.y.th, s.y.ph, s.y.pr, s.y.pth};
+        T k2[5], k3[5], k4[5], k5[5], k6[5], k7[5], tmp[5], nxt[5];
+        const T *k1 = s.k1;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * A21 * k1[i];
+        rhs5(k, rc, tmp, k2);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
+        rhs5(k, rc, tmp, k3);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]);
+        rhs5(k, rc, tmp, k4);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]);
+        rhs5(k, rc, tmp, k5);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            tmp[i] = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
+        rhs5(k, rc, tmp, k6);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) nxt[i] = y[i] + h * (B1 * k1[i] + B3 * k3[i] + B4 * k4[i] + B5 * k5[i] + B6 * k6[i]);
+        rhs5(k, rc, nxt, k7);
+
+        T mag = M<T>::abs(nxt[0]) + M<T>::abs(nxt[1]) + M<T>::abs(nxt[2]) + M<T>::abs(nxt[3]) + M<T>::abs(nxt[4]);
+        if (!(M<T>::finite(mag) && nxt[0] > T(0))) { // metrics.py:500-504
+            s.h *= T(0.25);
+            return s.h < h_min ? EV_INVALID : EV_RUNNING;
+        }
+        const T atol = rc.refine ? T(1e-10) : T(1e-8), rtol = rc.refine ? T(1e-8) : T(1e-6); // metrics.py:431-432
+        T err_sq = T(0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            T ei = h * (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
+            T sc = atol + rtol * M<T>::max(M<T>::abs(y[i]), M<T>::abs(nxt[i]));
+            T q = ei / sc;
+            err_sq += q * q;
+        }
+        T err = sqrt(err_sq / T(5));
+        if (err > T(1)) { // reject, metrics.py:516-522
+            s.h *= M<T>::max(T(0.2), T(0.9) * pow(err, T(-0.2)));
+            return s.h < h_min ? EV_INVALID : EV_RUNNING;
+        }
+        // accept
+        bool cap = y[0] > k.r_capture && nxt[0] <= k.r_capture;
+        bool esc = !cap && y[0] < k.r_escape && nxt[0] >= k.r_escape;
+        if (cap || esc) {
+            T target = cap ? k.r_capture : k.r_escape;
+            T denom = nxt[0] - y[0];
+            T frac = (denom == T(0)) ? T(1) : (target - y[0]) / denom;
+            frac = M<T>::min(M<T>::max(frac, T(0)), T(1));
+            s.y.r = y[0] + frac * (nxt[0] - y[0]);
+            s.y.th = y[1] + frac * (nxt[1] - y[1]);
+            s.y.ph = y[2] + frac * (nxt[2] - y[2]);
+            s.y.pr = y[3] + frac * (nxt[3] - y[3]);
+            s.y.pth = y[4] + frac * (nxt[4] - y[4]);
+            return cap ? EV_CAPTURED : EV_ESCAPED;
+        }
+        s.y.r = nxt[0]; s.y.th = nxt[1]; s.y.ph = nxt[2]; s.y.pr = nxt[3]; s.y.pth = nxt[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) s.k1[i] = k7[i];
+        s.lam += h;
+        s.h = (err < T(1e-10)) ? h * T(5) : h * M<T>::min(T(5), T(0.9) * pow(err, T(-0.2))); // metrics.py:561-564
+        return EV_RUNNING;
+    }
+};
+
+} // namespace lt

@@ -15,6 +15,7 @@
 // integrate an 8x8 pixel tile: neighbouring rays take nearly the same number of steps.
 #pragma once
 #include "lt_device.hpp"
+#include "lt_dp45.hpp"
 
 namespace lt {
 
@@ -46,6 +47,7 @@ struct MetricConsts { // float64 view of the metric for K1 / K3
     int kind;
     double M, a, r_obs, theta_obs, r_plus, r_capture, R_S;
     double phi_h; // Schwarzschild step h_max (to rebuild phi_f)
+    int evals_fixed, evals_per_step; // RHS evaluations: RK4 0 + 4/step, DP45 1 + 6/attempt
 };
 
 __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
@@ -293,8 +295,8 @@ __device__ __forceinline__ void store_fin(typename Vec4<T>::type *fin0, typename
 }
 
 // Direct schedule: one work-item per ray, a wavefront = one 8x8 tile.
-template <typename T>
-__global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
+template <typename T, typename Integ>
+__global__ void __launch_bounds__(256) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
                                                          uint4 *__restrict__ stamps)
@@ -306,12 +308,14 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k_in, con
     pin_consts(k);
     typename Vec4<T>::type rec = ic[q];
     int flags = (int)rec.w;
-    RayState<T> st;
-    ray_start(k, st, rec.x, rec.y);
+    typename Integ::State st;
+    st.y.r = k.r_obs; st.y.th = k.theta_obs; st.y.ph = T(0); st.y.pr = rec.x; st.y.pth = rec.y;
+    st.steps = 0;
     int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
     if (flags & FLAG_OK) {
         RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
-        do { ev = kerr_rk4_advance(k, rc, st); } while (ev == EV_RUNNING);
+        Integ::start(k, rc, st, rec.x, rec.y);
+        do { ev = Integ::advance(k, rc, st); } while (ev == EV_RUNNING);
     }
     uint32_t steps = st.steps;
     store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
@@ -327,8 +331,8 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_direct(KerrConsts<T> k_in, con
 // of its lanes idle).  A wave hosting a very long ray (a photon orbiting near the critical curve:
 // up to ~50x the mean step count) raises its issue priority so that the serial chain of that one
 // ray is not time-sliced 8 ways against bulk work.
-template <typename T>
-__global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
+template <typename T, typename Integ>
+__global__ void __launch_bounds__(256) k_kerr_queue(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                         typename Vec4<T>::type *__restrict__ fin0,
                                                         typename Vec4<T>::type *__restrict__ fin1, uint32_t n_q,
                                                         uint32_t *__restrict__ head, uint32_t chunk,
@@ -343,10 +347,9 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k_in, cons
     bool have = false;          // this lane holds a live ray
     uint32_t q = 0, total_steps = 0;
     int prio = 0;
-    RayState<T> st;
-    RayConsts<T> rc;
-    ray_start(k, st, T(0), T(0));
-    rc = make_ray_consts(k, T(0), false);
+    typename Integ::State st;
+    RayConsts<T> rc = make_ray_consts(k, T(0), false);
+    Integ::start(k, rc, st, T(0), T(0));
     for (;;) {
         uint64_t idle = __ballot(!have);
         uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -371,8 +374,8 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k_in, cons
                     typename Vec4<T>::type rec = ic[q];
                     int flags = (int)rec.w;
                     if (flags & FLAG_OK) {
-                        ray_start(k, st, rec.x, rec.y);
                         rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
+                        Integ::start(k, rc, st, rec.x, rec.y);
                         have = true;
                     } else { // padding or no valid initial condition: finished before it starts
                         store_fin<T>(fin0, fin1, q, k.r_obs, k.theta_obs, T(0), rec.x, rec.y, rec.z,
@@ -387,7 +390,7 @@ __global__ void __launch_bounds__(256) k_kerr_rk4_queue(KerrConsts<T> k_in, cons
             continue;
         }
         if (have) {
-            int ev = kerr_rk4_advance(k, rc, st);
+            int ev = Integ::advance(k, rc, st);
             if (ev != EV_RUNNING) {
                 store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
                 total_steps += st.steps;
@@ -508,7 +511,7 @@ __device__ __forceinline__ void load_result(const MetricConsts &m, const typenam
     } else {
         kerr_extract(m, (double)v0.x, (double)v0.y, (double)v0.z, (double)v0.w, (double)v1.x, (double)v1.y, ev, o);
     }
-    o.evals = o.steps * 4u;
+    o.evals = (uint32_t)m.evals_fixed + o.steps * (uint32_t)m.evals_per_step;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)

@@ -23,10 +23,10 @@ import numpy as np
 
 import ltrace
 
-# Backend defaults.  The north-star path is the float32 fixed-step RK4 kernel
-# (reference metrics.py:570-658); 'dp45' + 64 reproduces the reference's production
-# Kerr integrator (metrics.py:419-567).
-DEFAULT_KERR_INTEGRATOR = "rk4"
+# Backend defaults.  'dp45' (float64) is the reference's production Kerr integrator
+# (metrics.py:419-567) and therefore the drop-in default; 'rk4' + precision 32 is the north-star
+# kernel (reference metrics.py:570-658, float32), about 2.4x faster per ray -- what bench.py measures.
+DEFAULT_KERR_INTEGRATOR = "dp45"
 DEFAULT_PRECISION = 32
 DEFAULT_SCHEDULE = "direct"
 

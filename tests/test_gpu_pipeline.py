@@ -129,7 +129,29 @@ def test_traced_shadow_matches_oracle():
     al, _, _ = oracle.pixel_angles(256, 256, np.radians(40.0), np.radians(40.0))
     assert ((img == 0) != (al.astype(np.float64) < S.alpha_crit(50.0))).sum() <= 4
     assert stats["rays"] == 256 * 256
-    K = metrics.Kerr(1.0, 0.9)
+    K = metrics.Kerr(1.0, 0.9, integrator="rk4", precision=32)
     imgk, statusk, _ = black_hole_shadow.render_traced(K, 128, 128)
     ref = oracle.lookup("kerr", 1.0, 0.9, 50.0, 128, 128, np.radians(40.0), np.radians(40.0), integrator="rk4")
     assert ((statusk == 1) != (ref["status"] == 1)).sum() <= 16
+
+
+@pytest.mark.parametrize("name", ["4x6_a0p9", "48x64_a0p9", "48x64_a0p9_psi", "33x40_a0p9"])
+def test_production_pipeline_matches_reference_lookups(name):
+    """The reference's default Kerr pipeline end to end -- DP45 float64, TB mirror, axis-refine
+    columns, psi offsets -- against the lookups and images the reference itself produced (F4/F5)."""
+    g, m = _g(name)
+    fov, psi = (m["hfov"], m["vfov"]), tuple(m["psi"])
+    K = metrics.Kerr(1.0, m["a"], integrator="dp45")
+    al = image_lens.build_alpha_lookup((m["h"], m["w"]), fov, psi=psi)
+    fa, wd, total, traced = image_lens.precompute_final_alpha_lookup_2d(al, fov, m["alpha_crit"], m["r_obs"], K, psi=psi)
+    assert (total, traced) == (m["total"], m["traced"])
+    nan_same = np.isnan(fa) == np.isnan(g["final_alpha"])
+    assert (~nan_same).sum() <= 1
+    both = ~np.isnan(fa) & ~np.isnan(g["final_alpha"])
+    assert np.max(np.abs(fa[both] - g["final_alpha"][both])) <= 5e-6
+    assert (wd[nan_same] != g["winding"][nan_same]).sum() <= 1
+    img = image_lens.render_lensed_image(g["background"], al, fa, wd, m["alpha_crit"], fov, psi=psi)
+    assert np.all(img == g["lensed"], axis=-1).mean() >= 0.995
+    # fused call, same settings
+    fused = image_lens.render_frame(g["background"], K, m["r_obs"], fov, psi=psi, tb_symmetry=True)
+    assert np.array_equal(fused["fa"], fa, equal_nan=True) and np.array_equal(fused["rgb"], img)
