@@ -376,9 +376,10 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             static const int k2_block = [] { int b = env_int("LT_K2_BLOCK", 64);
                                              return (b == 64 || b == 128 || b == 256) ? b : 64; }();
             unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
+            static const int long_iters = env_int("LT_D_LONG", 1024);
             if ((rc = sd.begin((size_t)(n_q / 64)))) return rc;
-            if constexpr (sizeof(T) == 8) { if (dp45) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, sd.dev); }
-            if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, sd.dev);
+            if constexpr (sizeof(T) == 8) { if (dp45) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev); }
+            if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev);
         } else {
             if (n_q >= (int64_t)1 << 32) return fail(LT_ERR_UNSUPPORTED, "queue schedule: more than 2^32 rays");
             int cus;

@@ -299,7 +299,7 @@ template <typename T, typename Integ>
 __global__ void __launch_bounds__(256) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
-                                                         uint4 *__restrict__ stamps)
+                                                         uint32_t long_iters, uint4 *__restrict__ stamps)
 {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
@@ -315,7 +315,14 @@ __global__ void __launch_bounds__(256) k_kerr_direct(KerrConsts<T> k_in, const t
     if (flags & FLAG_OK) {
         RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
         Integ::start(k, rc, st, rec.x, rec.y);
-        do { ev = Integ::advance(k, rc, st); } while (ev == EV_RUNNING);
+        // A wave still running after `long_iters` iterations hosts one of the few very long rays (the
+        // launch cannot end before they do): it raises its issue priority over the bulk waves sharing
+        // its SIMD.  The iteration counter is wave-uniform (SGPR), so the check costs no VALU.
+        uint32_t it = 0;
+        do {
+            ev = Integ::advance(k, rc, st);
+            if (++it == long_iters) __builtin_amdgcn_s_setprio(3);
+        } while (ev == EV_RUNNING);
     }
     uint32_t steps = st.steps;
     store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);

@@ -345,3 +345,40 @@ def test_dp45_needs_float64():
     fa, nh, oc = metrics.Kerr(1.0, 0.9, integrator="dp45").trace_ray(50.0, 0.15, 0.7)
     assert oc == "escaped" and nh == 1 and abs(fa - 0.6227281296517803) < 1e-8       # SURVEY 8c KAT
     assert metrics.Kerr(1.0, 0.99, integrator="dp45").trace_ray(50.0, 0.09, -np.pi / 2)[2] == "captured"
+
+
+def test_kerr_8192_near_extremal_frame():
+    """BASELINE config 5 shape on one GPU (Kerr a = 0.99, 8192^2 = 67 M rays, float32): every pixel
+    accounted for, and the strided subsample (every 32nd pixel = the 256^2 frame of the same camera)
+    agrees with the oracle within the float32 budget stated for a = 0.99."""
+    size = 8192
+    cam = _cam(size, size, 50.0)
+    out = ltrace.render(cam, ltrace.Metric(1, 0, 1.0, 0.99), ltrace.default_opts(precision=32), want=("fa", "status"))
+    st = out["stats"]
+    assert st["rays"] == size * size == st["escaped"] + st["captured"] + st["invalid"]
+    small = oracle.lookup("kerr", 1.0, 0.99, 50.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
+    k = size // 256
+    sub_fa, sub_st = out["fa"][::k, ::k], out["status"][::k, ::k]
+    assert ((sub_st == 1) != (small["status"] == 1)).sum() <= 66
+    both = (sub_st == 1) & (small["status"] == 1)
+    d = np.abs(sub_fa[both].astype(np.float64) - small["fa"][both])
+    assert np.median(d) <= 5e-6 and np.quantile(d, 0.99) <= 1e-4
+    assert abs((out["status"] != 1).mean() - (small["status"] != 1).mean()) < 0.01
+
+
+def test_image_lens_4096_lensed_background():
+    """BASELINE config 4 shape (image_lens default observer r_obs = 100 M, 4096^2, background image):
+    the colouring of the GPU's own lookup equals the oracle's renderer bit for bit at full size, far
+    pixels are an identity-like mapping, and the RGBA8 frame is the truncated float image."""
+    n = 4096
+    cam = _cam(n, n, 100.0)
+    bg = _background(n, n, 11)
+    out = ltrace.render(cam, ltrace.Metric(1, 0, 1.0, 0.9), ltrace.default_opts(precision=32), background=bg,
+                        want=("fa", "winding", "rgb", "rgba", "status"))
+    img = oracle.render(bg, out["fa"], out["winding"], cam.hfov, cam.vfov)
+    assert np.array_equal(out["rgb"], img)
+    assert np.array_equal(out["rgba"][..., :3], (out["rgb"] * np.float32(255.0)).astype(np.uint8))
+    assert np.all(out["rgba"][..., 3] == 255)
+    assert np.all(out["rgb"][out["status"] != 1] == 0)           # captured / invalid -> black
+    # corners: deflection ~ 4M/b is a few pixels there, never the identity, never out of frame by much
+    assert out["stats"]["rays"] == n * n and (out["status"] == 1).mean() > 0.97
