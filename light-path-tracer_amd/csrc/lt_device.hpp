@@ -82,6 +82,16 @@ template <> struct M<float> {
         s = __uint_as_float(__float_as_uint(ss) ^ sbit);
         c = __uint_as_float(__float_as_uint(cc) ^ cbit);
     }
+    // sin and cos of a SMALL angle (|d| <= 0.25): Taylor, 7 FMA-class instructions, error < 1.3e-8
+    static __device__ __forceinline__ void sincos_small(float d, float &s, float &c)
+    {
+        float z = d * d;
+        float ps = __builtin_fmaf(z, 8.3333333333e-3f, -1.6666666667e-1f);
+        s = __builtin_fmaf(ps * z, d, d);
+        float pc = __builtin_fmaf(z, -1.3888888889e-3f, 4.1666666667e-2f);
+        pc = __builtin_fmaf(pc, z, -0.5f);
+        c = __builtin_fmaf(pc, z, 1.0f);
+    }
     // true unless x is NaN or +-inf
     static __device__ __forceinline__ bool finite(float x) { return __builtin_fabsf(x) < __builtin_inff(); }
 };
@@ -133,6 +143,22 @@ template <> struct M<double> {
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
     static __device__ __forceinline__ double sin2_floor(double s) { return __builtin_fmax(s * s, 1e-15); }
     static __device__ __forceinline__ void sincos(double x, double &s, double &c) { sincos_f64(x, s, c); }
+    // |d| <= 0.25: Taylor to d^11 / d^12, error < 3e-18
+    static __device__ __forceinline__ void sincos_small(double d, double &s, double &c)
+    {
+        double z = d * d;
+        double ps = __builtin_fma(z, -2.50521083854417188e-08, 2.75573192239858907e-06);
+        ps = __builtin_fma(ps, z, -1.98412698412698413e-04);
+        ps = __builtin_fma(ps, z, 8.33333333333333333e-03);
+        ps = __builtin_fma(ps, z, -1.66666666666666667e-01);
+        s = __builtin_fma(ps * z, d, d);
+        double pc = __builtin_fma(z, 2.08767569878680990e-09, -2.75573192239858907e-07);
+        pc = __builtin_fma(pc, z, 2.48015873015873016e-05);
+        pc = __builtin_fma(pc, z, -1.38888888888888889e-03);
+        pc = __builtin_fma(pc, z, 4.16666666666666667e-02);
+        pc = __builtin_fma(pc, z, -0.5);
+        c = __builtin_fma(pc, z, 1.0);
+    }
     static __device__ __forceinline__ bool finite(double x) { return __builtin_fabs(x) < __builtin_inf(); }
 };
 
@@ -200,11 +226,9 @@ __device__ __forceinline__ RayConsts<T> make_ray_consts(const KerrConsts<T> &k, 
 // (metrics.py:228-231): every output carries the factor 1/Sigma, so masking that one factor (and
 // evaluating at max(r, r_cut) so nothing overflows) does it.
 template <typename T>
-__device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T th, T pr, T pth,
-                                         T &dr, T &dth, T &dph, T &dpr, T &dpth)
+__device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T s, T c, T pr, T pth,
+                                            T &dr, T &dth, T &dph, T &dpr, T &dpth)
 {
-    T s, c;
-    M<T>::sincos(th, s, c);
     bool inside = r_in <= k.r_cut;
     T r = inside ? k.r_cut : r_in;
     T s2 = M<T>::sin2_floor(s);
@@ -236,6 +260,37 @@ __device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts
     dpth = (T(2) * mhiS) * (s * c) * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2));
 }
 
+template <typename T>
+__device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts<T> &rc, T r, T th, T pr, T pth,
+                                         T &dr, T &dth, T &dph, T &dpr, T &dpth)
+{
+    T s, c;
+    M<T>::sincos(th, s, c);
+    kerr_rhs_sc(k, rc, r, s, c, pr, pth, dr, dth, dph, dpr, dpth);
+}
+
+// sin and cos of th0 + d from (s0, c0) = sincos(th0): the stage states of a Runge-Kutta step differ from
+// the step's base state by h * (a small angular velocity), so the 25-instruction argument reduction +
+// polynomials shrink to an 11-instruction rotation.  The wave falls back to the full evaluation in the
+// rare step where some lane's |d| exceeds 0.25 rad (wave-uniform branch).
+template <typename T>
+__device__ __forceinline__ void sincos_shift(T th0, T s0, T c0, T d, T &s, T &c)
+{
+    T sd, cd;
+    M<T>::sincos_small(d, sd, cd);
+    s = M<T>::fma(s0, cd, c0 * sd);
+    c = M<T>::fma(c0, cd, -(s0 * sd));
+    bool big = M<T>::abs(d) > T(0.25);
+    if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+        // which formula a lane uses depends on ITS angle only, never on its neighbours: results stay
+        // bit-identical however rays are grouped into waves (direct vs queue schedule, partitions)
+        T sf, cf;
+        M<T>::sincos(th0 + d, sf, cf);
+        s = big ? sf : s;
+        c = big ? cf : c;
+    }
+}
+
 template <typename T> struct State5 {
     T r, th, ph, pr, pth;
 };
@@ -248,22 +303,24 @@ __device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const
 {
     T k_r, k_th, k_ph, k_pr, k_pth;
     T a_r, a_th, a_ph, a_pr, a_pth; // running k1 + 2 k2 + 2 k3 + k4
-    kerr_rhs(k, rc, y.r, y.th, y.pr, y.pth, k_r, k_th, k_ph, k_pr, k_pth);
+    T s0, c0, s, c;
+    M<T>::sincos(y.th, s0, c0); // the only full sincos of the step; stages rotate it (sincos_shift)
+    kerr_rhs_sc(k, rc, y.r, s0, c0, y.pr, y.pth, k_r, k_th, k_ph, k_pr, k_pth);
     a_r = k_r; a_th = k_th; a_ph = k_ph; a_pr = k_pr; a_pth = k_pth;
     T hh = T(0.5) * h;
-    T t_r = M<T>::fma(hh, k_r, y.r), t_th = M<T>::fma(hh, k_th, y.th);
-    T t_pr = M<T>::fma(hh, k_pr, y.pr), t_pth = M<T>::fma(hh, k_pth, y.pth);
-    kerr_rhs(k, rc, t_r, t_th, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    T t_r = M<T>::fma(hh, k_r, y.r), t_pr = M<T>::fma(hh, k_pr, y.pr), t_pth = M<T>::fma(hh, k_pth, y.pth);
+    sincos_shift(y.th, s0, c0, hh * k_th, s, c);
+    kerr_rhs_sc(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
     a_r = M<T>::fma(T(2), k_r, a_r); a_th = M<T>::fma(T(2), k_th, a_th); a_ph = M<T>::fma(T(2), k_ph, a_ph);
     a_pr = M<T>::fma(T(2), k_pr, a_pr); a_pth = M<T>::fma(T(2), k_pth, a_pth);
-    t_r = M<T>::fma(hh, k_r, y.r); t_th = M<T>::fma(hh, k_th, y.th);
-    t_pr = M<T>::fma(hh, k_pr, y.pr); t_pth = M<T>::fma(hh, k_pth, y.pth);
-    kerr_rhs(k, rc, t_r, t_th, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    t_r = M<T>::fma(hh, k_r, y.r); t_pr = M<T>::fma(hh, k_pr, y.pr); t_pth = M<T>::fma(hh, k_pth, y.pth);
+    sincos_shift(y.th, s0, c0, hh * k_th, s, c);
+    kerr_rhs_sc(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
     a_r = M<T>::fma(T(2), k_r, a_r); a_th = M<T>::fma(T(2), k_th, a_th); a_ph = M<T>::fma(T(2), k_ph, a_ph);
     a_pr = M<T>::fma(T(2), k_pr, a_pr); a_pth = M<T>::fma(T(2), k_pth, a_pth);
-    t_r = M<T>::fma(h, k_r, y.r); t_th = M<T>::fma(h, k_th, y.th);
-    t_pr = M<T>::fma(h, k_pr, y.pr); t_pth = M<T>::fma(h, k_pth, y.pth);
-    kerr_rhs(k, rc, t_r, t_th, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    t_r = M<T>::fma(h, k_r, y.r); t_pr = M<T>::fma(h, k_pr, y.pr); t_pth = M<T>::fma(h, k_pth, y.pth);
+    sincos_shift(y.th, s0, c0, h * k_th, s, c);
+    kerr_rhs_sc(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
     T h6 = h * T(1.0 / 6.0);
     State5<T> o;
     o.r = M<T>::fma(h6, a_r + k_r, y.r);
