@@ -31,6 +31,7 @@ template <typename T> struct Rk4 {
 template <typename T> struct Dp45State {
     State5<T> y;
     T k1[5];       // FSAL: derivative at y
+    T s0, c0;      // sin / cos of y.th, carried like k1 (the stages rotate it: sincos_shift)
     T lam, h;
     uint32_t steps; // step attempts (accepted + rejected), metrics.py:454
 };
@@ -39,16 +40,19 @@ template <typename T> struct Dp45 {
     using State = Dp45State<T>;
     static constexpr int EVALS_FIXED = 1, EVALS_PER_STEP = 6;
 
-    static __device__ __forceinline__ void rhs5(const KerrConsts<T> &k, const RayConsts<T> &rc, const T *y, T *d)
+    // right-hand side at stage state y, whose polar angle is th0 + dth with (s0, c0) = sincos(th0)
+    static __device__ __forceinline__ void rhs5(const KerrConsts<T> &k, const RayConsts<T> &rc, const T *y, T th0, T s0,
+                                                T c0, T dth, T *d, T &s, T &c)
     {
-        kerr_rhs(k, rc, y[0], y[1], y[3], y[4], d[0], d[1], d[2], d[3], d[4]);
+        sincos_shift(th0, s0, c0, dth, s, c);
+        kerr_rhs_sc(k, rc, y[0], s, c, y[3], y[4], d[0], d[1], d[2], d[3], d[4]);
     }
 
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, T p_r, T p_th)
     {
         s.y.r = k.r_obs; s.y.th = k.theta_obs; s.y.ph = T(0); s.y.pr = p_r; s.y.pth = p_th;
-        T y[5] = {s.y.r, s.y.th, s.y.ph, s.y.pr, s.y.pth};
-        rhs5(k, rc, y, s.k1);                               // metrics.py:446
+        M<T>::sincos(s.y.th, s.s0, s.c0);
+        kerr_rhs_sc(k, rc, s.y.r, s.s0, s.c0, s.y.pr, s.y.pth, s.k1[0], s.k1[1], s.k1[2], s.k1[3], s.k1[4]); // metrics.py:446
         s.lam = T(0);
         s.h = M<T>::max(T(1), T(0.01) * k.r_obs);           // metrics.py:449
         s.steps = 0;
@@ -74,25 +78,27 @@ template <typename T> struct Dp45 {
         const T y[5] = {s.y.r, s.y.th, s.y.ph, s.y.pr, s.y.pth};
         T k2[5], k3[5], k4[5], k5[5], k6[5], k7[5], tmp[5], nxt[5];
         const T *k1 = s.k1;
+        T ss, cc, sn, cn; // stage sin / cos; (sn, cn) belong to the candidate next state
+        const T th0 = y[1], s0 = s.s0, c0 = s.c0;
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * A21 * k1[i];
-        rhs5(k, rc, tmp, k2);
+        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k2, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
-        rhs5(k, rc, tmp, k3);
+        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k3, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]);
-        rhs5(k, rc, tmp, k4);
+        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k4, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]);
-        rhs5(k, rc, tmp, k5);
+        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k5, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             tmp[i] = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
-        rhs5(k, rc, tmp, k6);
+        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k6, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) nxt[i] = y[i] + h * (B1 * k1[i] + B3 * k3[i] + B4 * k4[i] + B5 * k5[i] + B6 * k6[i]);
-        rhs5(k, rc, nxt, k7);
+        rhs5(k, rc, nxt, th0, s0, c0, nxt[1] - th0, k7, sn, cn);
 
         T mag = M<T>::abs(nxt[0]) + M<T>::abs(nxt[1]) + M<T>::abs(nxt[2]) + M<T>::abs(nxt[3]) + M<T>::abs(nxt[4]);
         if (!(M<T>::finite(mag) && nxt[0] > T(0))) { // metrics.py:500-504
@@ -131,6 +137,7 @@ template <typename T> struct Dp45 {
         s.y.r = nxt[0]; s.y.th = nxt[1]; s.y.ph = nxt[2]; s.y.pr = nxt[3]; s.y.pth = nxt[4];
 #pragma unroll
         for (int i = 0; i < 5; ++i) s.k1[i] = k7[i];
+        s.s0 = sn; s.c0 = cn; // FSAL for the trigonometry too
         s.lam += h;
         s.h = (err < T(1e-10)) ? h * T(5) : h * M<T>::min(T(5), T(0.9) * pow(err, T(-0.2))); // metrics.py:561-564
         return EV_RUNNING;
