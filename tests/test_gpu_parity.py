@@ -382,3 +382,51 @@ def test_image_lens_4096_lensed_background():
     assert np.all(out["rgb"][out["status"] != 1] == 0)           # captured / invalid -> black
     # corners: deflection ~ 4M/b is a few pixels there, never the identity, never out of frame by much
     assert out["stats"]["rays"] == n * n and (out["status"] == 1).mean() > 0.97
+
+
+def test_inclined_observer_and_grayscale_fused():
+    """theta_obs != pi/2 (the reference never passes it but its integrators take it, metrics.py:148,
+    and keep the -x exit-angle convention, quirk Q4) and a grayscale background through lt_render."""
+    W, H = 96, 80
+    vfov = np.radians(40.0)
+    hfov = 2 * np.arctan(np.tan(vfov / 2) * W / H)
+    cam = ltrace.Camera(W, H, hfov, vfov, 0.0, 0.0, 50.0, 1.0)
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    gray = _background(H, W, 2)[..., 0].copy()
+    for precision, med, p99 in ((64, 1e-7, 5e-7), (32, 5e-6, 1e-4)):
+        out = ltrace.render(cam, met, ltrace.default_opts(integrator="rk4", precision=precision, tb_symmetry=1), background=gray)
+        ref = oracle.lookup("kerr", 1.0, 0.9, 50.0, H, W, hfov, vfov, theta_obs=1.0, integrator="rk4", tb_symmetry=True)
+        assert ref["traced"] == W * H == out["stats"]["rays"]          # no mirror off the equator
+        assert ((out["status"] == 1) != (ref["status"] == 1)).sum() <= 8
+        both = (out["status"] == 1) & (ref["status"] == 1)
+        d = np.abs(out["fa"][both].astype(np.float64) - ref["fa"][both])
+        assert np.median(d) <= med and np.quantile(d, 0.99) <= p99
+        assert out["rgb"].shape == (H, W)
+        np.testing.assert_array_equal(out["rgb"], oracle.render(gray, out["fa"], out["winding"], hfov, vfov))
+
+
+def test_kerr_zero_spin_limit_and_bardeen_edges():
+    """KAT-3: Kerr(a=0) through the Kerr RK4 kernel agrees with the Schwarzschild orbit-equation
+    kernel (<= 2e-5 rad).  KAT-4: on the equatorial row of an a = 0.9 frame the
+    shadow edges bracket Bardeen's prograde / retrograde critical impact parameters
+    (xi = 2.8444, -6.8323; reference metrics.py:866-891)."""
+    K0 = metrics.Kerr(1.0, 0.0, integrator="rk4", precision=64)
+    S = metrics.Schwarzschild(1.0, precision=64)
+    for al in (0.103, 0.11, 0.15, 0.3):
+        fk, nk, ok = K0.trace_ray(50.0, al, 0.7)
+        fs, ns, os_ = S.trace_ray(50.0, al)
+        assert ok == os_ == "escaped" and nk == ns and abs(fk - fs) < 2e-5
+    assert K0.trace_ray(50.0, 0.05, 0.3)[2] == "captured"
+    n = 1024
+    cam = _cam(n, n, 50.0)
+    out = ltrace.render(cam, ltrace.Metric(1, 0, 1.0, 0.9), ltrace.default_opts(precision=32), want=("status",))
+    row = out["status"][n // 2] != 1                     # y_cam = 0: the equatorial row
+    xs = np.nonzero(row)[0]
+    fx = (n / 2) / np.tan(cam.hfov / 2)
+    # impact parameter of a pixel on that row: b = r sin(alpha) sqrt(Sigma/Delta), alpha = atan(|x_cam|)
+    r_obs, a = 50.0, 0.9
+    conv = r_obs * np.sqrt(r_obs**2 / (r_obs**2 - 2 * r_obs + a * a))
+    b_left = np.sin(np.arctan((n / 2 - xs.min()) / fx)) * conv
+    b_right = np.sin(np.arctan((xs.max() - n / 2) / fx)) * conv
+    lo, hi = sorted((b_left, b_right))
+    assert abs(lo - 2.8444) < 0.12 and abs(hi - 6.8323) < 0.12, (b_left, b_right)
