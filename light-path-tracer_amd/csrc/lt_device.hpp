@@ -230,7 +230,9 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
                                             T &dr, T &dth, T &dph, T &dpr, T &dpth)
 {
     bool inside = r_in <= k.r_cut;
-    T r = inside ? k.r_cut : r_in;
+    const bool any_inside = __ballot(inside) != 0ull; // almost never: only a stage of the last steps before capture
+    T r = r_in;
+    if (__builtin_expect(any_inside, 0)) r = inside ? k.r_cut : r_in;
     T s2 = M<T>::sin2_floor(s);
     T r2 = r * r;
     T Sigma = M<T>::fma(k.a2 * c, c, r2);
@@ -240,7 +242,7 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     T iS = (Delta * s2) * t;
     T iD = (Sigma * s2) * t;
     T is2 = SD * t;
-    iS = inside ? T(0) : iS;
+    if (__builtin_expect(any_inside, 0)) iS = inside ? T(0) : iS;
     T P = r2 + rc.c_P;
     T q = P * iD;
     T Lis2 = rc.L * is2;
