@@ -150,6 +150,39 @@ LT_PROBE_KERNEL(k_probe_fma_neg, I_FMA_NEG)
 LT_PROBE_KERNEL(k_probe_mul_e64, I_MUL_E64)
 LT_PROBE_KERNEL(k_probe_fma3_rcp, I_FMA_RCP)
 
+
+// packed (two floats per lane per instruction) chains: 8 independent register PAIRS per lane
+#define LT_PROBE_KERNEL_PK(NAME, INS)                                                     \
+    __global__ void __launch_bounds__(256) NAME(int iters, float sc, float *sink)          \
+    {                                                                                      \
+        typedef float v2f __attribute__((ext_vector_type(2)));                             \
+        float x = threadIdx.x * 1e-3f + 1.0f;                                              \
+        v2f a0 = {x, x + 1}, a1 = {x + 2, x + 3}, a2 = {x + 4, x + 5}, a3 = {x + 6, x + 7}; \
+        v2f a4 = {x + 8, x + 9}, a5 = {x + 10, x + 11}, a6 = {x + 12, x + 13}, a7 = {x + 14, x + 15}; \
+        v2f m = {0.999f + x * 1e-6f, 0.998f}, b = {1e-3f + x * 1e-7f, 2e-3f};                \
+        unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
+        for (int i = 0; i < iters; ++i) {                                                  \
+            LT_PROBE_BODY8(INS) LT_PROBE_BODY8(INS) LT_PROBE_BODY8(INS) LT_PROBE_BODY8(INS) \
+            LT_PROBE_BODY8(INS) LT_PROBE_BODY8(INS) LT_PROBE_BODY8(INS) LT_PROBE_BODY8(INS) \
+        }                                                                                  \
+        unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+        v2f s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                     \
+        if (s.x + s.y == 12345.678f) sink[0] = s.x;                                        \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                         \
+            ((unsigned long long *)sink)[2] = c1 - c0;                                     \
+            ((unsigned long long *)sink)[3] = r1 - r0;                                     \
+        }                                                                                  \
+    }
+#define I_PK_FMA(N) "v_pk_fma_f32 %" #N ", %" #N ", %8, %9"
+#define I_PK_MUL(N) "v_pk_mul_f32 %" #N ", %" #N ", %8"
+#define I_PK_ADD(N) "v_pk_add_f32 %" #N ", %" #N ", %9"
+#define I_PK_DEP_FMA(N) "v_pk_fma_f32 %0, %0, %8, %9"
+#define I_PK_FMA_FMA(N) "v_pk_fma_f32 %" #N ", %" #N ", %8, %9\n\tv_fma_f32 %" #N ", %" #N ", %8, %9"
+LT_PROBE_KERNEL_PK(k_probe_pk_fma, I_PK_FMA)
+LT_PROBE_KERNEL_PK(k_probe_pk_mul, I_PK_MUL)
+LT_PROBE_KERNEL_PK(k_probe_pk_add, I_PK_ADD)
+LT_PROBE_KERNEL_PK(k_probe_pk_dep_fma, I_PK_DEP_FMA)
+
 struct ProbeEntry {
     const char *name;
     void (*kernel)(int, float, float *);
@@ -177,6 +210,8 @@ static const ProbeEntry g_probes[] = {
     {"rcp,7fma,dep-fma", k_probe_rcpd7, 9},
     {"rcp,14fma,dep-fma", k_probe_rcpd14, 16},
     {"rcp,28fma,dep-fma", k_probe_rcpd28, 30},
+    {"v_pk_fma_f32", k_probe_pk_fma, 1}, {"v_pk_mul_f32", k_probe_pk_mul, 1}, {"v_pk_add_f32", k_probe_pk_add, 1},
+    {"dep v_pk_fma_f32", k_probe_pk_dep_fma, 1},
     {"fma+max", k_probe_p1, 2}, {"2fma+max", k_probe_p2, 3}, {"fma+mul(sgpr)", k_probe_p3, 2},
     {"cmp+cnd+2fma", k_probe_p4, 4}, {"3fma+cvt", k_probe_p5, 4}, {"fma+rcp+fma+max", k_probe_p6, 4}, {"max+rcp", k_probe_p7, 2},
 };

@@ -312,10 +312,12 @@ def test_queue_schedule_is_bit_identical_to_direct(precision):
 @pytest.mark.parametrize("schedule", ["direct", "queue"])
 def test_batch_dp45_matches_reference(name, schedule):
     """GPU DP45 (float64) vs the reference's own per-ray outputs of _kerr_trace_ray_numba
-    (metrics.py:419-567).  The GPU right-hand side is an algebraic re-derivation, so accepted
-    step sizes differ in the last bits; a ray agrees to ~1e-10 unless an accept/reject decision
-    sits within rounding of err_norm = 1, in which case it moves by about the integrator's own
-    tolerance (rtol 1e-6): median 1e-10, p99 1e-7, max 1e-4 rad; <= 2e-4 of rays change class."""
+    (metrics.py:419-567).  The GPU evaluates the step-size controller (error scale reciprocal,
+    err^-0.2) in float32, so its step sizes follow the reference's to ~1e-7 relative and the exit
+    angles to a few 1e-9 rad (measured median 2.7e-9, p99 1e-8 -- three orders below the
+    integrator's own rtol 1e-6); a ray whose accept/reject decision sits within 1e-7 of
+    err_norm = 1 moves by about that rtol.  Budget: median 1e-8, p99 1e-7, max 1e-4 rad;
+    <= 2e-4 of rays change class; RHS evaluation counts equal on all but <= 1e-3 of rays."""
     g = _load(name)
     meta = json.loads(str(g["meta"]))
     n = g["alpha"].size
@@ -328,7 +330,8 @@ def test_batch_dp45_matches_reference(name, schedule):
     assert (~same_class).sum() <= max(1, int(2e-4 * n))
     esc = same_class & (st == 1)
     d = np.abs(fa[esc] - g["final_alpha"][esc])
-    assert np.median(d) <= 1e-10 and np.quantile(d, 0.99) <= 1e-7 and d.max() <= 1e-4, (np.median(d), np.quantile(d, 0.99), d.max())
+    assert np.median(d) <= 1e-8 and np.quantile(d, 0.99) <= 1e-7 and d.max() <= 1e-4, (np.median(d), np.quantile(d, 0.99), d.max())
+    assert (ev.astype(np.int64) != g["rhs_evals"]).sum() <= max(2, int(1e-3 * n))
     same = st == g["status"]
     assert (w[same] != g["n_half"][same]).sum() <= max(2, int(2e-4 * n))
     assert abs(ev.mean() - g["rhs_evals"].mean()) <= 2e-3 * g["rhs_evals"].mean()
