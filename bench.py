@@ -37,10 +37,12 @@ import sharding  # noqa: E402
 
 # As-written flop counts of the reference
 F_RK4_STEP = 4 * 188 + 80     # 832 per RK4 step   (metrics.py:221-323)
+F_DP45_ATTEMPT = 6 * 188 + 320  # 1448 per DP45 step attempt (metrics.py:454-564); + 188 once for the FSAL seed
 F_KERR_FIXED = 95 + 72        # 167 per ray        (metrics.py:148-218, :363-416)
 F_SCHW_STEP = 54
 F_SCHW_FIXED = 45
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+PEAK_FP64_VALU_TFLOPS = 78.6   # float64 vector rate = half the float32 one
 
 
 def parse():
@@ -163,7 +165,10 @@ def main():
     rays_per_frame = c[ltrace.STAT_RAYS] // steps
     rk_steps = c[ltrace.STAT_STEPS] / steps
     if args.metric == "kerr":
-        flops_frame = rk_steps * F_RK4_STEP + rays_per_frame * F_KERR_FIXED
+        if args.integrator == "dp45":
+            flops_frame = rk_steps * F_DP45_ATTEMPT + rays_per_frame * (F_KERR_FIXED + 188)
+        else:
+            flops_frame = rk_steps * F_RK4_STEP + rays_per_frame * F_KERR_FIXED
     else:
         flops_frame = rk_steps * F_SCHW_STEP + rays_per_frame * F_SCHW_FIXED
     ms_per_step = elapsed / steps * 1e3
@@ -183,6 +188,7 @@ def main():
             pass
         integ_ms = float(kern_max[1].item()) / steps          # slowest rank's average integrate-kernel time
         achieved = (flops_frame / world) / (integ_ms * 1e-3) / 1e12 if integ_ms > 0 else 0.0
+        peak = PEAK_FP32_VALU_TFLOPS if args.precision == 32 else PEAK_FP64_VALU_TFLOPS
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -195,9 +201,9 @@ def main():
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
                        "invalid": c[ltrace.STAT_INVALID] // steps},
-            "roofline": {"bound": "valu_fp32", "kernel": f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_VALU_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "valu_fp32" if args.precision == 32 else "valu_fp64", "kernel": f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct",
+                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "algorithmic_flops_per_launch": int(flops_frame / world),
                          "avg_launch_ms": round(integ_ms, 4),
                          "other_kernels_ms": {"prologue": round(float(kern_max[0].item()) / steps, 4),
