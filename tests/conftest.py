@@ -17,6 +17,13 @@ os.environ.setdefault("MPLBACKEND", "Agg")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # built artefacts are git-ignored: a fresh checkout has no libltrace_hip.so / oracle yet.
+    # hipcc cross-compiles without a GPU, so build them once here if they are missing.
+    lib = os.path.join(PKG, "lib", "libltrace_hip.so")
+    ora = os.path.join(ROOT, "oracle", "liblt_oracle.so")
+    if not (os.path.exists(lib) and os.path.exists(ora)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def _has_gpu():
