@@ -68,7 +68,7 @@ def test_main_plumbing(tmp_path, capsys):
     out = tmp_path / "geo.png"
     sol, outcome = main_script.main(output=str(out))
     text = capsys.readouterr().out
-    assert outcome == "escaped" and "Impact parameter:   b = 7.1021 M" in text
+    assert outcome == "escaped" and "Impact parameter:   b = 7.1021 M" in text and "Outcome:            ESCAPED" in text
     assert out.exists() and out.stat().st_size > 1000
     black_hole_shadow.main(output=str(tmp_path / "shadow.png"), width=64, height=64)
     assert (tmp_path / "shadow.png").exists()
@@ -134,3 +134,17 @@ def test_tile_queue_order_is_a_bijection():
             assert 0 <= t[0] < tx and 0 <= t[1] < ty and t not in seen
             seen.add(t)
             assert t2q(c, *t) == pos
+
+
+def test_geodesic_tracer_demo_table(golden_dir, tmp_path, capsys):
+    """KAT-1: the reference's demo table (geodesic_tracer.py:153-172) -- critical angle 5.8442 deg, five
+    captured and five escaped rays, impact parameters as printed there."""
+    rows = geodesic_tracer.demo(output=str(tmp_path / "fan.png"))
+    text = capsys.readouterr().out
+    assert "Critical viewing angle: 5.8442°" in text
+    with open(os.path.join(golden_dir, "scalars.json")) as f:
+        b_ref = json.load(f)["schw_b"]
+    for deg, b, outcome in rows:
+        assert outcome == ("captured" if deg <= 5.5 else "escaped")
+        assert b == pytest.approx(b_ref[str(deg)], abs=1e-12)
+    assert (tmp_path / "fan.png").exists()
