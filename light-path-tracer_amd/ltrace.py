@@ -211,6 +211,8 @@ def global_rows(height, row_block, n_parts, part):
 def render(cam, metric, opts, background=None, want=("fa", "winding", "status", "steps", "rgb", "rgba")):
     """Host-pointer frame render (lt_render).  Returns dict of numpy arrays + 'stats'."""
     rows = local_rows(cam.height, opts.row_block or 16, opts.n_parts or 1, opts.part)
+    if rows < 0 or cam.width <= 0:
+        raise LtraceError(ERR_INVALID_ARG, f"bad frame {cam.width}x{cam.height} or partition {opts.part}/{opts.n_parts}")
     W = cam.width
     bg = None
     nch = 3

@@ -433,3 +433,36 @@ def test_kerr_zero_spin_limit_and_bardeen_edges():
     b_right = np.sin(np.arctan((xs.max() - n / 2) / fx)) * conv
     lo, hi = sorted((b_left, b_right))
     assert abs(lo - 2.8444) < 0.12 and abs(hi - 6.8323) < 0.12, (b_left, b_right)
+
+
+def test_c_abi_error_codes():
+    """Error behaviour of the boundary: bad arguments are refused with LT_ERR_INVALID_ARG /
+    LT_ERR_UNSUPPORTED and a message, nothing is written, and the library stays usable."""
+    cam = _cam(64, 48, 50.0)
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    cases = [
+        (ltrace.Camera(0, 48, 1.0, 0.7, 0, 0, 50.0, np.pi / 2), met, ltrace.default_opts(), ltrace.ERR_INVALID_ARG),
+        (cam, ltrace.Metric(1, 0, 1.0, 1.2), ltrace.default_opts(), ltrace.ERR_INVALID_ARG),       # |a| > M
+        (cam, ltrace.Metric(7, 0, 1.0, 0.0), ltrace.default_opts(), ltrace.ERR_INVALID_ARG),       # unknown metric
+        (cam, ltrace.Metric(1, 0, -1.0, 0.0), ltrace.default_opts(), ltrace.ERR_INVALID_ARG),      # M <= 0
+        (cam, met, ltrace.default_opts(precision=16), ltrace.ERR_INVALID_ARG),
+        (cam, met, ltrace.default_opts(integrator=5), ltrace.ERR_INVALID_ARG),
+        (cam, met, ltrace.default_opts(schedule=9), ltrace.ERR_INVALID_ARG),
+        (cam, met, ltrace.default_opts(n_parts=4, part=4), ltrace.ERR_INVALID_ARG),
+        (cam, met, ltrace.default_opts(integrator="dp45", precision=32), ltrace.ERR_UNSUPPORTED),
+        (cam, met, ltrace.default_opts(tb_symmetry=1, n_parts=2, part=0), ltrace.ERR_UNSUPPORTED),
+    ]
+    for c, m, o, code in cases:
+        with pytest.raises(ltrace.LtraceError) as ei:
+            ltrace.render(c, m, o, want=("status",))
+        assert ei.value.code == code and len(str(ei.value)) > 30
+    with pytest.raises(ValueError):
+        ltrace.render(cam, met, ltrace.default_opts(), background=np.zeros((10, 10, 3), np.float32))
+    with pytest.raises(ValueError):
+        ltrace.trace_batch_schw(1.0, 50.0, np.zeros(8), np.zeros(4), np.zeros(8, dtype=np.int64))   # wrong out size
+    out = ltrace.render(cam, met, ltrace.default_opts(), want=("status",))                           # still alive
+    assert out["stats"]["rays"] == 64 * 48
+    # a partition that owns no rows is legal and empty
+    o = ltrace.default_opts(n_parts=8, part=7, row_block=16)
+    empty = ltrace.render(_cam(32, 40, 50.0), met, o, want=("status", "rgba"))
+    assert empty["status"].shape == (0, 32) and empty["stats"]["rays"] == 0
