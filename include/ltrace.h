@@ -186,6 +186,46 @@ int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t height, int32_
                         int32_t elem_bytes, int32_t row_block, int32_t n_parts, int32_t part,
                         void *stream);
 
+/* ---- batched dense trajectories ------------------------------------------------------------- *
+ * Replaces geodesic_tracer.integrate_geodesic (geodesic_tracer.py:22-71) -- solve_ivp(RK45) on     *
+ * metric.geodesic_equations (metrics.py:763-790 / :946-1029) with a capture and an escape radius   *
+ * event -- for n 8-D initial states (t, r, theta, phi, p_t, p_r, p_theta, p_phi) at once, as      *
+ * metric.initial_conditions returns them (metrics.py:792-808 / :1032-1107).  float64.              */
+typedef struct lt_dense_opts {
+    double lambda_max;   /* affine range, geodesic_tracer.py:22 (1000)                                  */
+    double r_stop_inner; /* < 0: the metric's capture radius 1.01 r_plus (geodesic_tracer.py:43-44)     */
+    double r_stop_outer; /* < 0: twice each track's start radius (geodesic_tracer.py:45-46)             */
+    double rtol, atol;   /* geodesic_tracer.py:64-65 (1e-8, 1e-10)                                      */
+    double max_step;     /* geodesic_tracer.py:63 (1.0)                                                 */
+    int64_t max_points;  /* record capacity per track (>= 2)                                            */
+    int32_t max_attempts; /* guard against a track that never ends (status -2); solve_ivp has none      */
+    int32_t reserved;
+    void *stream;        /* hipStream_t; NULL = the default stream                                      */
+} lt_dense_opts;
+void lt_default_dense_opts(lt_dense_opts *o);
+
+/* Track status: which of solve_ivp's endings the track took. */
+#define LT_TRACK_RANGE_END 0   /* lambda_max reached (solve_ivp status 0)        */
+#define LT_TRACK_CAPTURE_EVENT 1 /* r fell through r_stop_inner (status 1, event 0) */
+#define LT_TRACK_ESCAPE_EVENT 2  /* r rose through r_stop_outer (status 1, event 1) */
+#define LT_TRACK_FAILED (-1)     /* step size underflow (solve_ivp status -1)       */
+#define LT_TRACK_ATTEMPT_LIMIT (-2)
+
+/* HOST pointers.  state0 (n, 8).  Records are point-major so that device stores coalesce:
+ *   out_t (max_points, n), out_y (max_points, 8, n): track i's k-th point is out_t[k*n + i],
+ *   out_y[(k*8 + c)*n + i] -- solution.t[k], solution.y[c, k] of the reference.
+ *   out_count (n): points of the complete record.  If it exceeds max_points only the first
+ *   max_points - 1 points are kept and the last slot holds the final point.
+ *   out_status (n): LT_TRACK_*.   out_nfev (n): right-hand-side evaluations (solution.nfev). */
+int lt_integrate_dense(const lt_metric *metric, const lt_dense_opts *opts, const double *state0, int64_t n,
+                       double *out_t, double *out_y, int32_t *out_count, int8_t *out_status, int32_t *out_nfev);
+/* Same with DEVICE pointers, asynchronous on opts->stream. */
+int lt_integrate_dense_dev(const lt_metric *metric, const lt_dense_opts *opts, const double *d_state0, int64_t n,
+                           double *d_out_t, double *d_out_y, int32_t *d_out_count, int8_t *d_out_status,
+                           int32_t *d_out_nfev);
+/* Device probe of the 8-D right-hand side for parity tests: states (n, 8) -> out (n, 8), host pointers. */
+int lt_rhs8_probe(const lt_metric *metric, const double *states, int64_t n, double *out);
+
 /* Sum of HIP-event times (ms) of the prologue / integrate / epilogue kernels over all
  * lt_render_dev calls made with opts->timing != 0 since the last collect; *calls = how many.
  * Synchronises on the recorded events. */

@@ -6,6 +6,7 @@
 #include "../../include/ltrace.h"
 #include "lt_kernels.hpp"
 #include "lt_probe.hpp"
+#include "lt_dense.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -896,3 +897,4 @@ extern "C" int lt_piece_probe(int piece, int waves_per_simd, int iters, double *
 }
 
 #include "lt_api_stages.inc"
+#include "lt_api_dense.inc"

@@ -1,0 +1,283 @@
+// lt_dense.hpp -- batched dense trajectories: the other side of the metric plugin.
+//
+// Replaces, for a whole batch of 8-D initial states, geodesic_tracer.integrate_geodesic
+// (geodesic_tracer.py:22-71): solve_ivp(RK45, max_step, rtol, atol, two terminal radius events,
+// dense_output) on metric.geodesic_equations (metrics.py:763-790 Schwarzschild, :946-1029 Kerr).
+// One work-item per track, float64 throughout, every accepted point written to HBM.
+//
+// The integrator is scipy's (a dependency of the reference, not part of its tree); what is built here
+// is its published algorithm -- Dormand-Prince 5(4), Hairer's initial step, the 0.9 err^(-1/5) controller
+// on an RMS norm, Shampine's 4th-order dense output, Brent's method for the event time -- so that the
+// step sequence (point count, nfev) equals solve_ivp's and the points agree to ~1e-9.
+//
+// Record layout: point-major, track-minor --  t[p * n + i],  y[(p * 8 + c) * n + i] --
+// so that the 64 tracks of a wavefront write 64 consecutive doubles per store instruction whenever
+// they are at the same point index (they mostly are: max_step paces every track alike).
+#pragma once
+#include "lt_device.hpp"
+
+namespace lt {
+
+struct DenseConsts {
+    double M, a, a2, r_zero; // r_zero = 1.001 r_plus: the right-hand side is zero inside (metrics.py:767, :950)
+    int floor_sin2;          // Schwarzschild class floors sin^2 at 1e-15 (metrics.py:774-775); Kerr's 8-D form does not
+    double lambda_max, r_in, r_out; // r_in < 0: never; r_out < 0: twice the track's start radius (geodesic_tracer.py:45-46)
+    double rtol, atol, max_step;
+    int64_t n, max_points;
+    int32_t max_attempts; // guard: a track that needs more step attempts ends with status -2 (solve_ivp has no such limit)
+};
+
+// 8-D Hamilton equations of H = g^{mu nu} p_mu p_nu / 2 in Boyer-Lindquist coordinates, state
+// (t, r, theta, phi, p_t, p_r, p_theta, p_phi).  Same separable form as the 5-D one of lt_device.hpp
+// (2 Sigma H = Delta p_r^2 + p_theta^2 + D^2 / sin^2 - P^2 / Delta, D = L - a E sin^2, P = E (r^2 + a^2) - a L)
+// with the energy E = -p_t a state variable, and the exact gradient: the 2H terms are kept, so the function
+// equals the reference's for any state, on shell or not.
+__device__ __forceinline__ void rhs8(const DenseConsts &k, const double *y, double *d)
+{
+    const double r = y[1], E = -y[4], pr = y[5], pth = y[6], L = y[7];
+    if (r <= k.r_zero) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = 0.0;
+        return;
+    }
+    double s, c;
+    M<double>::sincos(y[2], s, c);
+    double s2 = s * s;
+    if (k.floor_sin2 && s2 < 1e-15) s2 = 1e-15;
+    const double r2 = r * r, ra = r2 + k.a2;
+    const double Sigma = r2 + k.a2 * c * c, Delta = ra - 2.0 * k.M * r;
+    const double iS = 1.0 / Sigma, iD = 1.0 / Delta, is2 = 1.0 / s2;
+    const double P = E * ra - k.a * L, D = L - k.a * E * s2;
+    const double PD = P * iD, Ds = D * is2;
+    const double F = Delta * pr * pr + pth * pth + D * Ds - P * PD; // 2 Sigma H
+    const double H2 = F * iS;                                       // 2 H
+    d[0] = (k.a * D + ra * PD) * iS;
+    d[1] = Delta * pr * iS;
+    d[2] = pth * iS;
+    d[3] = (Ds + k.a * PD) * iS;
+    d[4] = 0.0;
+    const double Dr = 2.0 * r - 2.0 * k.M;
+    const double Fr = Dr * (pr * pr + PD * PD) - 4.0 * r * E * PD;
+    d[5] = -0.5 * (Fr - H2 * 2.0 * r) * iS;
+    const double sc2 = 2.0 * s * c;
+    const double Fth = -sc2 * Ds * (2.0 * k.a * E + Ds);
+    d[6] = -0.5 * (Fth + H2 * k.a2 * sc2) * iS;
+    d[7] = 0.0;
+}
+
+__device__ __forceinline__ double rms8(const double *x)
+{
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i] * x[i];
+    return __builtin_sqrt(s) * 0.35355339059327373; // / sqrt(8)
+}
+
+// radius of the dense output y(t) = y_old + h Q [x, x^2, x^3, x^4] minus the event radius
+__device__ __forceinline__ double dense_r(double r_old, double t_old, double h, const double *Qr, double t, double radius)
+{
+    double x = (t - t_old) / h;
+    double p = ((Qr[3] * x + Qr[2]) * x + Qr[1]) * x + Qr[0];
+    return r_old + h * (p * x) - radius;
+}
+
+// Brent's method on [xa, xb] to 4 eps (solve_ivp's brentq call)
+__device__ inline double brent_root(double r_old, double t_old, double h, const double *Qr, double radius, double xa, double xb)
+{
+    const double tol = 4.0 * 2.220446049250313e-16;
+    double xpre = xa, xcur = xb, xblk = 0, fblk = 0, spre = 0, scur = 0;
+    double fpre = dense_r(r_old, t_old, h, Qr, xpre, radius), fcur = dense_r(r_old, t_old, h, Qr, xcur, radius);
+    if (fpre == 0) return xpre;
+    if (fcur == 0) return xcur;
+    for (int it = 0; it < 100; ++it) {
+        if (fpre != 0 && fcur != 0 && ((fpre < 0) != (fcur < 0))) {
+            xblk = xpre; fblk = fpre;
+            spre = scur = xcur - xpre;
+        }
+        if (fabs(fblk) < fabs(fcur)) {
+            xpre = xcur; xcur = xblk; xblk = xpre;
+            fpre = fcur; fcur = fblk; fblk = fpre;
+        }
+        double delta = (tol + tol * fabs(xcur)) * 0.5;
+        double sbis = (xblk - xcur) * 0.5;
+        if (fcur == 0 || fabs(sbis) < delta) return xcur;
+        if (fabs(spre) > delta && fabs(fcur) < fabs(fpre)) {
+            double stry;
+            if (xpre == xblk) {
+                stry = -fcur * (xcur - xpre) / (fcur - fpre);
+            } else {
+                double dpre = (fpre - fcur) / (xpre - xcur), dblk = (fblk - fcur) / (xblk - xcur);
+                stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));
+            }
+            if (2.0 * fabs(stry) < fmin(fabs(spre), 3.0 * fabs(sbis) - delta)) { spre = scur; scur = stry; }
+            else { spre = sbis; scur = sbis; }
+        } else {
+            spre = sbis; scur = sbis;
+        }
+        xpre = xcur; fpre = fcur;
+        xcur += (fabs(scur) > delta) ? scur : (sbis > 0 ? delta : -delta);
+        fcur = dense_r(r_old, t_old, h, Qr, xcur, radius);
+    }
+    return xcur;
+}
+
+struct DenseOut {
+    double *t;        // (max_points, n)
+    double *y;        // (max_points, 8, n)
+    int32_t *count;   // points a complete record holds (> max_points: truncated, last slot = final point)
+    int8_t *status;   // 1 capture event, 2 escape event, 0 lambda_max reached, -1 step size underflow, -2 attempt limit
+    int32_t *nfev;    // right-hand-side evaluations, counted like solve_ivp's nfev
+};
+
+__global__ void __launch_bounds__(64) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= k.n) return;
+    // Dormand-Prince tableau (Dormand & Prince 1980) and Shampine's dense-output matrix
+    constexpr double A21 = 1.0 / 5, A31 = 3.0 / 40, A32 = 9.0 / 40, A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9,
+                     A51 = 19372.0 / 6561, A52 = -25360.0 / 2187, A53 = 64448.0 / 6561, A54 = -212.0 / 729,
+                     A61 = 9017.0 / 3168, A62 = -355.0 / 33, A63 = 46732.0 / 5247, A64 = 49.0 / 176, A65 = -5103.0 / 18656;
+    constexpr double B1 = 35.0 / 384, B3 = 500.0 / 1113, B4 = 125.0 / 192, B5 = -2187.0 / 6784, B6 = 11.0 / 84;
+    constexpr double E1 = -71.0 / 57600, E3 = 71.0 / 16695, E4 = -71.0 / 1920, E5 = 17253.0 / 339200, E6 = -22.0 / 525, E7 = 1.0 / 40;
+    constexpr double P[7][4] = {
+        {1, -8048581381.0 / 2820520608, 8663915743.0 / 2820520608, -12715105075.0 / 11282082432},
+        {0, 0, 0, 0},
+        {0, 131558114200.0 / 32700410799, -68118460800.0 / 10900136933, 87487479700.0 / 32700410799},
+        {0, -1754552775.0 / 470086768, 14199869525.0 / 1410260304, -10690763975.0 / 1880347072},
+        {0, 127303824393.0 / 49829197408, -318862633887.0 / 49829197408, 701980252875.0 / 199316789632},
+        {0, -282668133.0 / 205662961, 2019193451.0 / 616988883, -1453857185.0 / 822651844},
+        {0, 40617522.0 / 29380423, -110615467.0 / 29380423, 69997945.0 / 29380423}};
+
+    double y[8], f[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) y[c] = state0[i * 8 + c];
+    const double r_in = k.r_in, r_out = k.r_out < 0 ? 2.0 * y[1] : k.r_out;
+    double t = 0.0;
+    int32_t n_pts = 0, nfev = 0;
+    int status = 0;
+    auto push = [&](double tt, const double *yy) {
+        int64_t slot = n_pts < k.max_points ? n_pts : k.max_points - 1;
+        o.t[slot * k.n + i] = tt;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o.y[(slot * 8 + c) * k.n + i] = yy[c];
+        ++n_pts;
+    };
+    push(t, y);
+    rhs8(k, y, f); ++nfev;
+    double h_abs;
+    { // initial step (Hairer, Norsett, Wanner II.4), error-estimator order 4
+        double v[8], sc[8], y1[8], f1[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { sc[c] = k.atol + fabs(y[c]) * k.rtol; v[c] = y[c] / sc[c]; }
+        double d0 = rms8(v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = f[c] / sc[c];
+        double d1 = rms8(v);
+        double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+        h0 = fmin(h0, k.lambda_max);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) y1[c] = y[c] + h0 * f[c];
+        rhs8(k, y1, f1); ++nfev;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = (f1[c] - f[c]) / sc[c];
+        double d2 = rms8(v) / h0;
+        double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 0.2);
+        h_abs = fmin(fmin(100.0 * h0, h1), fmin(k.lambda_max, k.max_step));
+    }
+    double g_in = y[1] - r_in, g_out = y[1] - r_out;
+    int32_t attempts = 0;
+    while (t != k.lambda_max) {
+        const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+        h_abs = h_abs > k.max_step ? k.max_step : (h_abs < min_step ? min_step : h_abs);
+        bool rejected = false, failed = false;
+        double h, t_new, yn[8], k2[8], k3[8], k4[8], k5[8], k6[8], k7[8], tmp[8];
+        for (;;) {
+            if (h_abs < min_step || ++attempts > k.max_attempts) { failed = true; break; }
+            t_new = t + h_abs;
+            if (t_new - k.lambda_max > 0) t_new = k.lambda_max;
+            h = t_new - t;
+            h_abs = fabs(h);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * h;
+            rhs8(k, tmp, k2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * h;
+            rhs8(k, tmp, k3);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * h;
+            rhs8(k, tmp, k4);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * h;
+            rhs8(k, tmp, k5);
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * h;
+            rhs8(k, tmp, k6);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) yn[c] = y[c] + h * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
+            rhs8(k, yn, k7);
+            nfev += 6;
+            double e[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                double ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * h;
+                e[c] = ec / (k.atol + fmax(fabs(y[c]), fabs(yn[c])) * k.rtol);
+            }
+            const double err = rms8(e);
+            if (err < 1.0) {
+                double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                if (rejected) factor = fmin(1.0, factor);
+                h_abs *= factor;
+                break;
+            }
+            h_abs *= fmax(0.2, 0.9 * pow(err, -0.2)); // a NaN norm shrinks by 0.2, as in scipy (max(0.2, nan))
+            rejected = true;
+        }
+        if (failed) { status = attempts > k.max_attempts ? -2 : -1; break; }
+        const double gn_in = yn[1] - r_in, gn_out = yn[1] - r_out;
+        const bool hit_in = g_in >= 0 && gn_in <= 0, hit_out = g_out <= 0 && gn_out >= 0;
+        if (hit_in || hit_out) {
+            double Q[8][4];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    Q[c][j] = f[c] * P[0][j] + k3[c] * P[2][j] + k4[c] * P[3][j] + k5[c] * P[4][j] + k6[c] * P[5][j] + k7[c] * P[6][j];
+            double root_in = 0, root_out = 0;
+            if (hit_in) root_in = brent_root(y[1], t, h, Q[1], r_in, t, t_new);
+            if (hit_out) root_out = brent_root(y[1], t, h, Q[1], r_out, t, t_new);
+            const bool take_in = hit_in && (!hit_out || root_in <= root_out);
+            const double te = take_in ? root_in : root_out;
+            const double x = (te - t) / h, x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+            double ye[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ye[c] = y[c] + h * (Q[c][0] * x + Q[c][1] * x2 + Q[c][2] * x3 + Q[c][3] * x4);
+            push(te, ye);
+            status = take_in ? 1 : 2;
+            break;
+        }
+        g_in = gn_in; g_out = gn_out;
+        t = t_new;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { y[c] = yn[c]; f[c] = k7[c]; }
+        push(t, y);
+    }
+    o.count[i] = n_pts;
+    o.status[i] = (int8_t)status;
+    o.nfev[i] = nfev;
+}
+
+// probe of rhs8 for the parity tests
+__global__ void __launch_bounds__(64) k_rhs8_probe(DenseConsts k, const double *__restrict__ states, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= k.n) return;
+    double y[8], d[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) y[c] = states[i * 8 + c];
+    rhs8(k, y, d);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) out[i * 8 + c] = d[c];
+}
+
+} // namespace lt

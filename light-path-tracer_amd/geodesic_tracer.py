@@ -1,13 +1,22 @@
 """Dense single-ray integration and trajectory plots: the reference's geodesic_tracer.py surface
 (`integrate_geodesic`, `trace_ray`, `plot_trajectories`, the demo under __main__).
 
-This is the trajectory side of the metric plugin -- one to ten rays through scipy.solve_ivp on the
-metric's 8-D `geodesic_equations`, for plotting -- not the per-pixel path; it stays on the host
-(SURVEY 8f-3 ranks a batched GPU version as future work).  Units: G = c = 1.
+This is the trajectory side of the metric plugin.  Two ways through it:
+
+* `integrate_geodesic` / `trace_ray` -- one ray through scipy.solve_ivp on the metric's 8-D
+  `geodesic_equations`, exactly what the reference does (its callers trace one to ten rays for a plot).
+  Any Metric subclass works, including ones the GPU library knows nothing about.
+* `integrate_geodesics` / `trace_rays` -- a whole batch on the GPU (`lt_integrate_dense`: the same
+  Dormand-Prince 5(4) integrator, step controller, dense output and event location as solve_ivp's RK45,
+  float64, one work-item per track).  Schwarzschild and Kerr only; raises without a GPU.
+  `plot_trajectories(..., backend="hip")` draws from it.
+
+Units: G = c = 1.
 """
 import numpy as np
 from scipy.integrate import solve_ivp
 
+import ltrace
 from metrics import Schwarzschild
 
 # solve_ivp settings of the reference (geodesic_tracer.py:57-67)
@@ -36,6 +45,67 @@ def trace_ray(metric, r_obs, alpha, **kwargs):
     """Ray seen at viewing angle alpha from r_obs -> (solution, outcome), or (None, 'invalid')."""
     state0 = metric.initial_conditions(r_obs, alpha)
     return (None, "invalid") if state0 is None else integrate_geodesic(metric, state0, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------
+# the batched GPU path
+# ---------------------------------------------------------------------------------------------
+class Track:
+    """One trajectory of a GPU batch, with the fields the reference's callers read off solve_ivp's result:
+    t (n_points,), y (8, n_points) = rows t, r, theta, phi, p_t, p_r, p_theta, p_phi; status as solve_ivp
+    (1 a radius event ended it, 0 lambda_max reached, -1 failed), nfev, success.  `event` names the
+    event ('captured' / 'escaped' / None); `truncated` says the record did not fit `max_points` (then
+    the last point is still the final one)."""
+    __slots__ = ("t", "y", "status", "nfev", "event", "truncated", "success")
+
+    def __init__(self, t, y, code, nfev, truncated):
+        self.t, self.y, self.nfev, self.truncated = t, y, int(nfev), bool(truncated)
+        self.status = 1 if code in (ltrace.TRACK_CAPTURE_EVENT, ltrace.TRACK_ESCAPE_EVENT) else (0 if code == 0 else -1)
+        self.event = {ltrace.TRACK_CAPTURE_EVENT: "captured", ltrace.TRACK_ESCAPE_EVENT: "escaped"}.get(code)
+        self.success = self.status >= 0
+
+
+def _lt_metric(metric):
+    kind = getattr(metric, "is_spherically_symmetric", None)
+    if kind is None or not hasattr(metric, "M"):
+        raise TypeError("the GPU path integrates Schwarzschild and Kerr metrics only; use integrate_geodesic")
+    kerr = not kind
+    return ltrace.Metric(ltrace.METRIC_KERR if kerr else ltrace.METRIC_SCHWARZSCHILD, 0, float(metric.M),
+                         float(getattr(metric, "a", 0.0)) if kerr else 0.0)
+
+
+def integrate_geodesics(metric, states0, lambda_max=1000.0, r_stop_inner=None, r_stop_outer=None, max_points=1024,
+                        rtol=IVP["rtol"], atol=IVP["atol"], max_step=IVP["max_step"]):
+    """`integrate_geodesic` for a batch of 8-D initial states on the GPU -> list of (Track, outcome).
+    Defaults as there: stop at the metric's capture radius, at twice each track's start radius, or at
+    lambda_max.  The outcome rule is the reference's (final r <= 1.1 r_stop_inner: captured)."""
+    ltrace.require_gpu()
+    s0 = np.ascontiguousarray(states0, dtype=np.float64).reshape(-1, 8)
+    r_in = metric.capture_radius() if r_stop_inner is None else float(r_stop_inner)
+    opts = ltrace.default_dense_opts(lambda_max=float(lambda_max), r_stop_inner=r_in,
+                                     r_stop_outer=None if r_stop_outer is None else float(r_stop_outer),
+                                     rtol=float(rtol), atol=float(atol), max_step=float(max_step),
+                                     max_points=int(max_points))
+    t, y, count, status, nfev = ltrace.integrate_dense(_lt_metric(metric), s0, opts)
+    out = []
+    for i in range(s0.shape[0]):
+        m = min(int(count[i]), int(max_points))
+        trk = Track(t[:m, i].copy(), np.ascontiguousarray(y[:m, :, i].T), int(status[i]), nfev[i], count[i] > max_points)
+        out.append((trk, "captured" if trk.y[1, -1] <= 1.1 * r_in else "escaped"))
+    return out
+
+
+def trace_rays(metric, r_obs, alphas, thetas=None, **kwargs):
+    """`trace_ray` for many viewing angles at once on the GPU -> list of (Track, outcome) or (None, 'invalid')."""
+    alphas = np.atleast_1d(np.asarray(alphas, dtype=np.float64))
+    thetas = np.zeros_like(alphas) if thetas is None else np.broadcast_to(np.asarray(thetas, dtype=np.float64), alphas.shape)
+    states = [metric.initial_conditions(r_obs, al, th) for al, th in zip(alphas, thetas)]
+    live = [i for i, s in enumerate(states) if s is not None]
+    res = [(None, "invalid")] * len(states)
+    if live:
+        for i, r in zip(live, integrate_geodesics(metric, [states[i] for i in live], **kwargs)):
+            res[i] = r
+    return res
 
 
 # ---------------------------------------------------------------------------------------------
@@ -87,35 +157,40 @@ def save(fig, path, dpi=150, tight=False):
     plt.close(fig)
 
 
-def plot_trajectories(metric, r_obs, angles_deg, ax=None):
-    """Fan of equatorial tracks (x = r cos phi, y = r sin phi), one per viewing angle in degrees."""
+def plot_trajectories(metric, r_obs, angles_deg, ax=None, backend="scipy"):
+    """Fan of equatorial tracks (x = r cos phi, y = r sin phi), one per viewing angle in degrees.
+    backend "scipy": one solve_ivp per ray like the reference; "hip": the whole fan in one GPU launch."""
+    if backend not in ("scipy", "hip"):
+        raise ValueError("backend must be 'scipy' or 'hip'")
     if ax is None:
         _, ax = new_axes(10)
     draw_scene(ax, metric, r_obs)
-    for deg in angles_deg:
-        sol, outcome = trace_ray(metric, r_obs, np.radians(deg))
+    fan = trace_rays(metric, r_obs, np.radians(angles_deg)) if backend == "hip" else None
+    for j, deg in enumerate(angles_deg):
+        sol, outcome = fan[j] if fan is not None else trace_ray(metric, r_obs, np.radians(deg))
         if sol is not None:
             draw_track(ax, sol, outcome, f"α={deg}° ({outcome})")
     finish_axes(ax, f"Photon trajectories (critical angle ≈ {np.degrees(metric.alpha_crit(r_obs)):.2f}°)")
     return ax
 
 
-def demo(metric=None, r_obs=None, angles=DEMO_ANGLES, output="geodesic_trajectories.png"):
+def demo(metric=None, r_obs=None, angles=DEMO_ANGLES, output="geodesic_trajectories.png", backend="scipy"):
     metric = Schwarzschild(M=1.0) if metric is None else metric
     r_obs = 50.0 * metric.M if r_obs is None else r_obs
     bar = "=" * 60
     print(f"{bar}\nGeodesic Tracer\n{bar}\nMetric: {type(metric).__name__}\nObserver radius: r_obs = {r_obs} M")
     print(f"Critical viewing angle: {np.degrees(metric.alpha_crit(r_obs)):.4f}°\n{bar}\n\nTracing rays:\n" + "-" * 40)
     rows = []
-    for deg in angles:
+    fan = trace_rays(metric, r_obs, np.radians(angles)) if backend == "hip" else None
+    for j, deg in enumerate(angles):
         b = metric.viewing_angle_to_impact_parameter(np.radians(deg), r_obs)
-        _, outcome = trace_ray(metric, r_obs, np.radians(deg))
+        _, outcome = fan[j] if fan is not None else trace_ray(metric, r_obs, np.radians(deg))
         rows.append((deg, float(b), outcome))
         print(f"  α = {deg:6.2f}°  →  b = {b:6.3f} M  →  {'CAPTURED' if outcome == 'captured' else 'ESCAPED'}")
     if output:
         print("\nGenerating plot...")
         fig, ax = new_axes(12)
-        plot_trajectories(metric, r_obs, angles, ax=ax)
+        plot_trajectories(metric, r_obs, angles, ax=ax, backend=backend)
         ax.set_xlim(-0.3 * r_obs, 1.2 * r_obs)
         ax.set_ylim(-0.5 * r_obs, 0.5 * r_obs)
         save(fig, output, dpi=150, tight=True)
@@ -124,4 +199,9 @@ def demo(metric=None, r_obs=None, angles=DEMO_ANGLES, output="geodesic_trajector
 
 
 if __name__ == "__main__":
-    demo()
+    import argparse
+    ap = argparse.ArgumentParser(description="fan of photon trajectories around a Schwarzschild black hole")
+    ap.add_argument("--backend", choices=("scipy", "hip"), default="scipy")
+    ap.add_argument("--output", default="geodesic_trajectories.png")
+    args = ap.parse_args()
+    demo(backend=args.backend, output=args.output)

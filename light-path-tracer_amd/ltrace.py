@@ -49,6 +49,16 @@ class Opts(C.Structure):
                 ("stream", C.c_void_p), ("timing", C.c_int32), ("reserved", C.c_int32)]
 
 
+class DenseOpts(C.Structure):
+    _fields_ = [("lambda_max", C.c_double), ("r_stop_inner", C.c_double), ("r_stop_outer", C.c_double),
+                ("rtol", C.c_double), ("atol", C.c_double), ("max_step", C.c_double),
+                ("max_points", C.c_int64), ("max_attempts", C.c_int32), ("reserved", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+TRACK_RANGE_END, TRACK_CAPTURE_EVENT, TRACK_ESCAPE_EVENT, TRACK_FAILED, TRACK_ATTEMPT_LIMIT = 0, 1, 2, -1, -2
+
+
 class Stats(C.Structure):
     _fields_ = [("counters", C.c_uint64 * STAT_WORDS),
                 ("prologue_ms", C.c_double), ("integrate_ms", C.c_double), ("epilogue_ms", C.c_double)]
@@ -84,6 +94,12 @@ SIGNATURES = {
     "lt_pixel_angles": (C.c_int, [C.POINTER(Camera), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lt_shade": (C.c_int, [C.POINTER(Camera), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                            C.c_void_p, C.c_void_p]),
+    "lt_default_dense_opts": (None, [C.POINTER(DenseOpts)]),
+    "lt_integrate_dense": (C.c_int, [C.POINTER(Metric), C.POINTER(DenseOpts), C.c_void_p, C.c_int64, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_integrate_dense_dev": (C.c_int, [C.POINTER(Metric), C.POINTER(DenseOpts), C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lt_rhs8_probe": (C.c_int, [C.POINTER(Metric), C.c_void_p, C.c_int64, C.c_void_p]),
     "lt_valu_peak_probe": (C.c_int, [C.c_int, C.c_int, _dp]),
     "lt_valu_issue_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _dp, _dp]),
     "lt_valu_issue_probe_count": (C.c_int, []),
@@ -271,6 +287,48 @@ def shade(cam, background, fa, winding=None, loop_around=False, want_rgba=False)
     _check(load().lt_shade(C.byref(cam), int(bool(loop_around)), _np_ptr(bg), nch, _np_ptr(fa32), _np_ptr(wd),
                            _np_ptr(rgb), _np_ptr(rgba)))
     return (rgb, rgba) if want_rgba else rgb
+
+
+def default_dense_opts(**kw):
+    o = DenseOpts()
+    load().lt_default_dense_opts(C.byref(o))
+    for k, v in kw.items():
+        if v is not None:
+            setattr(o, k, v)
+    return o
+
+
+def integrate_dense(metric, state0, opts=None):
+    """Batched integrate_geodesic (lt_integrate_dense): state0 (n, 8) ->
+    (t (max_points, n), y (max_points, 8, n), count (n,), status (n,), nfev (n,)).
+    Track i is t[:m, i], y[:m, :, i].T with m = min(count[i], max_points)."""
+    o = opts or default_dense_opts()
+    s0 = np.ascontiguousarray(state0, dtype=np.float64).reshape(-1, 8)
+    n, mp = s0.shape[0], int(o.max_points)
+    if mp < 2:
+        raise LtraceError(ERR_INVALID_ARG, "max_points must be at least 2")
+    t = np.empty((mp, n), dtype=np.float64)
+    y = np.empty((mp, 8, n), dtype=np.float64)
+    count = np.zeros(n, dtype=np.int32)
+    status = np.zeros(n, dtype=np.int8)
+    nfev = np.zeros(n, dtype=np.int32)
+    _check(load().lt_integrate_dense(C.byref(metric), C.byref(o), _np_ptr(s0), n, _np_ptr(t), _np_ptr(y),
+                                     _np_ptr(count), _np_ptr(status), _np_ptr(nfev)))
+    return t, y, count, status, nfev
+
+
+def integrate_dense_dev(metric, opts, d_state0, n, d_t, d_y, d_count, d_status, d_nfev):
+    """Device-pointer form (integers, e.g. tensor.data_ptr()); asynchronous on opts.stream."""
+    _check(load().lt_integrate_dense_dev(C.byref(metric), C.byref(opts), C.c_void_p(d_state0), n, C.c_void_p(d_t),
+                                         C.c_void_p(d_y), C.c_void_p(d_count), C.c_void_p(d_status),
+                                         C.c_void_p(d_nfev)))
+
+
+def rhs8_probe(metric, states):
+    st = np.ascontiguousarray(states, dtype=np.float64).reshape(-1, 8)
+    out = np.empty_like(st)
+    _check(load().lt_rhs8_probe(C.byref(metric), _np_ptr(st), st.shape[0], _np_ptr(out)))
+    return out
 
 
 def stats_dict(counters, prologue_ms=0.0, integrate_ms=0.0, epilogue_ms=0.0):

@@ -65,6 +65,11 @@ def lib():
         L.lto_shadow_analytic.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
         L.lto_shadow_analytic.restype = None
         L.lto_num_threads.restype = C.c_int
+        L.lto_rhs8.argtypes = [C.c_int, C.c_double, C.c_double, _dp, _dp]
+        L.lto_rhs8.restype = None
+        L.lto_integrate_dense.argtypes = [C.c_int, C.c_double, C.c_double, _dp] + [C.c_double] * 6 + [
+            C.c_int64, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.lto_integrate_dense.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -202,3 +207,26 @@ def shadow_analytic(width, height, fov, alpha_crit):
     img = np.empty((width, height), dtype=np.float64)
     lib().lto_shadow_analytic(width, height, fov, alpha_crit, _ptr(img, _dp))
     return img
+
+
+def rhs8(kind, M, a, state):
+    """8-D right-hand side (metrics.py:763-790 kind 0, :946-1029 kind 1) of one state."""
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    out = np.empty(8, dtype=np.float64)
+    lib().lto_rhs8(int(kind), float(M), float(a), _ptr(st, _dp), _ptr(out, _dp))
+    return out
+
+
+def integrate_dense(kind, M, a, state0, lambda_max=1000.0, r_stop_inner=None, r_stop_outer=None,
+                    rtol=1e-8, atol=1e-10, max_step=1.0, max_points=4096):
+    """geodesic_tracer.integrate_geodesic (geodesic_tracer.py:22-71) for one 8-D initial state.
+    -> (t (n,), y (8, n), status, nfev); status 1 capture event, 2 escape event, 0 lambda_max, -1 failed."""
+    s0 = np.ascontiguousarray(state0, dtype=np.float64)
+    t = np.empty(max_points, dtype=np.float64)
+    y = np.empty((8, max_points), dtype=np.float64)
+    st, nfev = C.c_int(0), C.c_int64(0)
+    n = lib().lto_integrate_dense(int(kind), float(M), float(a), _ptr(s0, _dp), float(lambda_max), float(r_stop_inner),
+                                  float(r_stop_outer), float(rtol), float(atol), float(max_step), int(max_points),
+                                  _ptr(t, _dp), _ptr(y, _dp), C.byref(st), C.byref(nfev))
+    m = min(int(n), max_points)
+    return t[:m].copy(), y[:, :m].copy(), int(st.value), int(nfev.value)

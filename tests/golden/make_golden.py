@@ -22,6 +22,10 @@ SURVEY.md section 8(c):
   F6  psi_frame.npz       _psi_frame (image_lens.py:38-61), pixel_to_angles (:72-93)
   F7  scalars.json        alpha_crit, r_plus, impact parameters, single-ray KATs
   F8  solve_ivp.json      geodesic_tracer.trace_ray outcomes (geodesic_tracer.py:74-82)
+  F10 dense_tracks.npz    geodesic_tracer.integrate_geodesic (geodesic_tracer.py:22-71): every accepted
+                          solve_ivp point (t, 8-D y), nfev and outcome of 8-D initial states from
+                          metric.initial_conditions (metrics.py:792-808, :1032-1107), plus the 8-D
+                          right-hand sides (metrics.py:763-790, :946-1029) on random states
 
 The fixtures are data only (numbers in, numbers out); no reference source text
 is stored.  numba is absent in this container, so the reference runs through
@@ -333,6 +337,49 @@ def f8_ivp():
     print("  wrote solve_ivp.json")
 
 
+def f10_dense():
+    import geodesic_tracer as ref_gt
+    S, K9, K99 = ref_metrics.Schwarzschild(1.0), ref_metrics.Kerr(1.0, 0.9), ref_metrics.Kerr(1.0, 0.99)
+    jobs = []  # (metric id, M, a, r_obs, alpha, theta, kwargs)
+    for deg in (0, 2, 4, 5, 5.5, 5.97, 6.5, 8, 10, 15):
+        jobs.append((0, S, 50.0, np.radians(deg), 0.0, {}))
+    for deg in (0, 3, 6, 7.5, 7.7, 8.5, 12):
+        for th in (0.0, 0.9, np.pi / 2, 2.2, 4.0, 3 * np.pi / 2):
+            jobs.append((1, K9, 50.0, np.radians(deg), th, {}))
+    for deg, th in ((6.8, 1.3), (7.9, 4.71), (9.0, 0.2)):
+        jobs.append((2, K99, 50.0, np.radians(deg), th, {}))
+    # non-default stops: affine range ends first; caller-chosen radii; a far observer
+    jobs.append((0, S, 50.0, np.radians(8.0), 0.0, dict(lambda_max=30.0)))
+    jobs.append((1, K9, 50.0, np.radians(9.0), 1.0, dict(lambda_max=75.5)))
+    jobs.append((1, K9, 50.0, np.radians(10.0), 2.0, dict(r_stop_inner=6.0, r_stop_outer=60.0)))
+    jobs.append((0, S, 200.0, np.radians(1.6), 0.0, {}))
+    mid, Ma, state0, stops, offs, ts, ys, nfev, outcome, status = [], [], [], [], [0], [], [], [], [], []
+    for m_id, metric, r_obs, alpha, theta, kw in jobs:
+        s0 = metric.initial_conditions(r_obs, alpha, theta)
+        assert s0 is not None
+        sol, oc = ref_gt.integrate_geodesic(metric, s0, **kw)
+        mid.append(m_id); Ma.append((metric.M, getattr(metric, "a", 0.0)))
+        state0.append(s0)
+        stops.append((kw.get("lambda_max", 1000.0), kw.get("r_stop_inner", metric.capture_radius()),
+                      kw.get("r_stop_outer", 2.0 * s0[1])))
+        ts.append(sol.t); ys.append(sol.y); offs.append(offs[-1] + len(sol.t))
+        nfev.append(sol.nfev); outcome.append(1 if oc == "escaped" else -1); status.append(sol.status)
+    # 8-D right-hand sides on random (off-shell) states
+    rng = np.random.default_rng(10)
+    rs, ro = [], []
+    for metric in (S, K9, K99):
+        for _ in range(64):
+            r_lo = 1.02 * (metric.R_S if metric is S else metric.r_plus)
+            st = [rng.uniform(-5, 5), rng.uniform(r_lo, 120.0), rng.uniform(1e-3, np.pi - 1e-3), rng.uniform(-7, 7),
+                  rng.uniform(-1.5, -0.5), rng.uniform(-2, 2), rng.uniform(-8, 8), rng.uniform(-8, 8)]
+            rs.append(st); ro.append(np.asarray(metric.geodesic_equations(0.0, st), dtype=np.float64))
+    save("dense_tracks.npz", metric_id=np.array(mid, np.int32), M_a=np.array(Ma), state0=np.array(state0),
+         stops=np.array(stops), offsets=np.array(offs, np.int64), t=np.concatenate(ts),
+         y=np.concatenate(ys, axis=1), nfev=np.array(nfev, np.int64), outcome=np.array(outcome, np.int8),
+         ivp_status=np.array(status, np.int8), rhs_M_a=np.array([(1.0, 0.0)] * 64 + [(1.0, 0.9)] * 64 + [(1.0, 0.99)] * 64),
+         rhs_state=np.array(rs), rhs_out=np.array(ro))
+
+
 def f9_shadow():
     """black_hole_shadow.py analytic image (its main() only plots; restate the
     loop over the reference's own helper functions at a small size)."""
@@ -373,7 +420,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    todo = args.only.split(",") if args.only else ["F1", "F2", "F3", "F4", "F6", "F7", "F8", "F9"]
+    todo = args.only.split(",") if args.only else ["F1", "F2", "F3", "F4", "F6", "F7", "F8", "F9", "F10"]
     t0 = time.time()
     if "F1" in todo:
         print("F1"); f1_rhs()
@@ -387,6 +434,8 @@ def main():
         print("F8"); f8_ivp()
     if "F9" in todo:
         print("F9"); f9_shadow()
+    if "F10" in todo:
+        print("F10"); f10_dense()
     if "F4" in todo:
         print("F4"); f4_lookup()
     if "F3" in todo:

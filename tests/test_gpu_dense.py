@@ -1,0 +1,168 @@
+"""GPU parity of the batched dense-trajectory path (lt_integrate_dense), through the C-ABI.
+
+Checked against (i) the reference's own solve_ivp tracks (tests/golden/dense_tracks.npz, F10), (ii) the CPU
+oracle (oracle/lt_oracle_dense.c, itself pinned by F10) on seeded batches, (iii) properties at scale:
+every track ends on its event radius or at lambda_max, the Hamiltonian and the two cyclic momenta are
+conserved, the batch does not depend on how tracks are grouped.
+
+Tolerance (float64): points within 1e-8 of the reference's relative to 1 + |value| (the GPU evaluates an
+algebraically equivalent right-hand side with fused multiply-adds, which moves adaptive step sizes by
+~1e-11); the NUMBER of points and of right-hand-side evaluations must be equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import geodesic_tracer as gt
+import ltrace
+import metrics
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gold():
+    return np.load(os.path.join(GOLD, "dense_tracks.npz"), allow_pickle=False)
+
+
+def _metric(M, a, kerr):
+    return ltrace.Metric(ltrace.METRIC_KERR if kerr else ltrace.METRIC_SCHWARZSCHILD, 0, float(M), float(a))
+
+
+def test_rhs8_probe_matches_reference():
+    g = _gold()
+    for M, a in ((1.0, 0.0), (1.0, 0.9), (1.0, 0.99)):
+        sel = (g["rhs_M_a"][:, 1] == a)
+        out = ltrace.rhs8_probe(_metric(M, a, a != 0), g["rhs_state"][sel])
+        exp = g["rhs_out"][sel]
+        scale = np.max(np.abs(exp), axis=1, keepdims=True)
+        assert np.max(np.abs(out - exp) / scale) < 1e-12
+
+
+def test_tracks_match_reference_solve_ivp():
+    g = _gold()
+    off = g["offsets"]
+    worst = 0.0
+    for i in range(len(off) - 1):
+        M, a = g["M_a"][i]
+        lam, r_in, r_out = g["stops"][i]
+        o = ltrace.default_dense_opts(lambda_max=lam, r_stop_inner=r_in, r_stop_outer=r_out, max_points=1024)
+        t, y, count, status, nfev = ltrace.integrate_dense(_metric(M, a, g["metric_id"][i] > 0), g["state0"][i][None], o)
+        gt_, gy = g["t"][off[i]:off[i + 1]], g["y"][:, off[i]:off[i + 1]]
+        assert count[0] == len(gt_) and nfev[0] == g["nfev"][i], f"track {i}: {count[0]} vs {len(gt_)} points"
+        assert (status[0] in (1, 2)) == (g["ivp_status"][i] == 1)
+        m = count[0]
+        np.testing.assert_allclose(t[:m, 0], gt_, rtol=0, atol=1e-7)
+        err = np.max(np.abs(y[:m, :, 0].T - gy) / (1 + np.abs(gy)))
+        worst = max(worst, err)
+        assert err < 1e-8, f"track {i}"
+    print(f"worst relative point difference vs solve_ivp: {worst:.2e}")
+
+
+@pytest.mark.parametrize("kerr,a", [(False, 0.0), (True, 0.9), (True, 0.99)])
+def test_batch_matches_oracle(kerr, a):
+    """A seeded batch of 300 tracks in ONE launch against the oracle track by track."""
+    rng = np.random.default_rng(5)
+    met = metrics.Kerr(1.0, a) if kerr else metrics.Schwarzschild(1.0)
+    n = 300
+    alphas = rng.uniform(0.0, 0.35, n)
+    thetas = rng.uniform(0, 2 * np.pi, n) if kerr else np.zeros(n)
+    s0 = np.array([met.initial_conditions(50.0, al, th) for al, th in zip(alphas, thetas)])
+    o = ltrace.default_dense_opts(max_points=700)
+    t, y, count, status, nfev = ltrace.integrate_dense(_metric(1.0, a, kerr), s0, o)
+    r_plus = 1.0 + np.sqrt(1.0 - a * a)
+    same_steps = 0
+    for i in range(n):
+        ot, oy, ost, onfev = oracle.integrate_dense(int(kerr), 1.0, a, s0[i], 1000.0, 1.01 * r_plus, 2 * s0[i][1])
+        assert ost == status[i]
+        if len(ot) == count[i] and onfev == nfev[i]:
+            same_steps += 1
+            m = count[i]
+            assert np.max(np.abs(y[:m, :, i].T - oy) / (1 + np.abs(oy))) < 1e-8, f"track {i}"
+        else:  # an accept / reject decision within rounding of err = 1: the end point still agrees
+            assert abs(int(count[i]) - len(ot)) <= 2
+            np.testing.assert_allclose(y[min(count[i], 700) - 1, :, i], oy[:, -1], rtol=1e-6, atol=1e-6)
+    assert same_steps >= n - 3, f"{n - same_steps} tracks took a different step sequence"
+
+
+def test_large_batch_properties():
+    """65 536 Kerr tracks: endings, conservation laws, independence of the grouping."""
+    a, n = 0.9, 65536
+    rng = np.random.default_rng(11)
+    met = metrics.Kerr(1.0, a)
+    alphas = rng.uniform(0.01, 0.4, n)
+    thetas = rng.uniform(0, 2 * np.pi, n)
+    s0 = np.array([met.initial_conditions(50.0, al, th) for al, th in zip(alphas, thetas)])
+    MP = 384
+    o = ltrace.default_dense_opts(max_points=MP)
+    lm = _metric(1.0, a, True)
+    t, y, count_full, status, nfev = ltrace.integrate_dense(lm, s0, o)
+    assert np.all(status >= 1), "at r_obs = 50 every track ends on an event well inside lambda_max = 1000"
+    assert np.all(count_full >= 30) and np.mean(count_full > MP) < 1e-3  # a few near-critical tracks orbit for long
+    count = np.minimum(count_full, MP)
+    idx = np.arange(n)
+    last = y[count - 1, :, idx]                         # (n, 8) final points (kept even when truncated)
+    r_in = 1.01 * (1 + np.sqrt(1 - a * a))
+    target = np.where(status == 1, r_in, 100.0)
+    assert np.max(np.abs(last[:, 1] - target)) < 1e-9   # the event radius, located to 4 eps by Brent's method
+    assert np.all(last[:, 4] == -1.0) and np.all(last[:, 7] == s0[:, 7])  # cyclic momenta: exactly constant
+    # null condition along the track: H = g^{mu nu} p_mu p_nu / 2 stays at its start value (~0) to the tolerance
+    def hamiltonian(p):
+        r, th, pt, pr, pth, pph = p[:, 1], p[:, 2], p[:, 4], p[:, 5], p[:, 6], p[:, 7]
+        S = r * r + a * a * np.cos(th) ** 2; D = r * r - 2 * r + a * a; s2 = np.sin(th) ** 2
+        A = (r * r + a * a) ** 2 - a * a * D * s2
+        return 0.5 * (-A / (S * D) * pt * pt - 4 * a * r / (S * D) * pt * pph + D / S * pr * pr + pth * pth / S
+                      + (D - a * a * s2) / (S * D * s2) * pph * pph)
+    mid = y[count // 2, :, idx]
+    assert np.max(np.abs(hamiltonian(mid))) < 1e-6 and np.max(np.abs(hamiltonian(last))) < 1e-4
+    # times strictly increase along every track
+    assert np.all(np.diff(t, axis=0)[np.arange(MP - 1)[:, None] < (count - 1)[None, :]] > 0)
+    # grouping: a permuted batch gives bit-identical tracks
+    perm = rng.permutation(n)[:4096]
+    t2, y2, c2, st2, nf2 = ltrace.integrate_dense(lm, s0[perm], o)
+    assert np.array_equal(c2, count_full[perm]) and np.array_equal(st2, status[perm]) and np.array_equal(nf2, nfev[perm])
+    for j in (0, 17, 4095):
+        m = min(c2[j], MP)
+        assert np.array_equal(y2[:m, :, j], y[:m, :, perm[j]]) and np.array_equal(t2[:m, j], t[:m, perm[j]])
+
+
+def test_truncation_and_range_end():
+    met = metrics.Schwarzschild(1.0)
+    s0 = np.array([met.initial_conditions(50.0, np.radians(d)) for d in (8.0, 4.0)])
+    lm = _metric(1.0, 0.0, False)
+    full = ltrace.integrate_dense(lm, s0, ltrace.default_dense_opts(max_points=512))
+    cut = ltrace.integrate_dense(lm, s0, ltrace.default_dense_opts(max_points=16))
+    assert np.array_equal(full[2], cut[2]) and np.all(cut[2] > 16)       # counts report the complete record
+    for i in range(2):
+        assert np.array_equal(cut[1][:15, :, i], full[1][:15, :, i])       # first max_points - 1 points kept
+        assert np.array_equal(cut[1][15, :, i], full[1][full[2][i] - 1, :, i])  # last slot = final point
+    t, y, count, status, nfev = ltrace.integrate_dense(lm, s0, ltrace.default_dense_opts(lambda_max=30.0))
+    assert np.all(status == ltrace.TRACK_RANGE_END) and np.all(t[count - 1, np.arange(2)] == 30.0)
+
+
+def test_host_mirror_trace_rays_matches_scipy_path():
+    """geodesic_tracer.trace_rays (GPU) against geodesic_tracer.trace_ray (scipy on the package's own 8-D equations)."""
+    for met in (metrics.Schwarzschild(1.0), metrics.Kerr(1.0, 0.9)):
+        degs = [0, 2, 5.97, 8, 15, 95]
+        fan = gt.trace_rays(met, 50.0, np.radians(degs))
+        for deg, (trk, outcome) in zip(degs, fan):
+            sol, oc = gt.trace_ray(met, 50.0, np.radians(deg))
+            if sol is None:
+                assert trk is None and outcome == "invalid"
+                continue
+            assert outcome == oc and trk.nfev == sol.nfev and trk.t.shape == sol.t.shape and trk.status == sol.status
+            assert np.max(np.abs(trk.y - sol.y) / (1 + np.abs(sol.y))) < 1e-8
+
+
+def test_dense_error_codes():
+    lm = _metric(1.0, 0.0, False)
+    s0 = np.zeros((1, 8))
+    with pytest.raises(ltrace.LtraceError) as e:
+        ltrace.integrate_dense(_metric(1.0, 1.5, True), s0)
+    assert e.value.code == ltrace.ERR_INVALID_ARG
+    with pytest.raises(ltrace.LtraceError):
+        ltrace.integrate_dense(lm, s0, ltrace.default_dense_opts(rtol=-1.0))
+    out = ltrace.integrate_dense(lm, np.zeros((0, 8)))
+    assert out[2].size == 0
