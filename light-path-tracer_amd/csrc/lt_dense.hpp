@@ -129,7 +129,7 @@ struct DenseOut {
     int32_t *nfev;    // right-hand-side evaluations, counted like solve_ivp's nfev
 };
 
-__global__ void __launch_bounds__(64) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o)
+__global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= k.n) return;
@@ -237,21 +237,28 @@ __global__ void __launch_bounds__(64) k_dense_tracks(DenseConsts k, const double
         const double gn_in = yn[1] - r_in, gn_out = yn[1] - r_out;
         const bool hit_in = g_in >= 0 && gn_in <= 0, hit_out = g_out <= 0 && gn_out >= 0;
         if (hit_in || hit_out) {
-            double Q[8][4];
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
+            // dense output of this step, y(t) = y + h Q [x, x^2, x^3, x^4] with Q = K^T P: only the radius row is
+            // needed to locate the event; the other rows are formed one at a time afterwards (registers)
+            auto q_row = [&](int c, double *q) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    Q[c][j] = f[c] * P[0][j] + k3[c] * P[2][j] + k4[c] * P[3][j] + k5[c] * P[4][j] + k6[c] * P[5][j] + k7[c] * P[6][j];
+                    q[j] = f[c] * P[0][j] + k3[c] * P[2][j] + k4[c] * P[3][j] + k5[c] * P[4][j] + k6[c] * P[5][j] + k7[c] * P[6][j];
+            };
+            double Qr[4];
+            q_row(1, Qr);
             double root_in = 0, root_out = 0;
-            if (hit_in) root_in = brent_root(y[1], t, h, Q[1], r_in, t, t_new);
-            if (hit_out) root_out = brent_root(y[1], t, h, Q[1], r_out, t, t_new);
+            if (hit_in) root_in = brent_root(y[1], t, h, Qr, r_in, t, t_new);
+            if (hit_out) root_out = brent_root(y[1], t, h, Qr, r_out, t, t_new);
             const bool take_in = hit_in && (!hit_out || root_in <= root_out);
             const double te = take_in ? root_in : root_out;
             const double x = (te - t) / h, x2 = x * x, x3 = x2 * x, x4 = x3 * x;
             double ye[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) ye[c] = y[c] + h * (Q[c][0] * x + Q[c][1] * x2 + Q[c][2] * x3 + Q[c][3] * x4);
+            for (int c = 0; c < 8; ++c) {
+                double q[4];
+                q_row(c, q);
+                ye[c] = y[c] + h * (q[0] * x + q[1] * x2 + q[2] * x3 + q[3] * x4);
+            }
             push(te, ye);
             status = take_in ? 1 : 2;
             break;

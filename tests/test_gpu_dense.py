@@ -10,6 +10,7 @@ algebraically equivalent right-hand side with fused multiply-adds, which moves a
 ~1e-11); the NUMBER of points and of right-hand-side evaluations must be equal.
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -73,18 +74,25 @@ def test_batch_matches_oracle(kerr, a):
     o = ltrace.default_dense_opts(max_points=700)
     t, y, count, status, nfev = ltrace.integrate_dense(_metric(1.0, a, kerr), s0, o)
     r_plus = 1.0 + np.sqrt(1.0 - a * a)
-    same_steps = 0
+    same_steps, errs, cpu_s = 0, [], 0.0
     for i in range(n):
+        t0 = time.perf_counter()
         ot, oy, ost, onfev = oracle.integrate_dense(int(kerr), 1.0, a, s0[i], 1000.0, 1.01 * r_plus, 2 * s0[i][1])
+        cpu_s += time.perf_counter() - t0
         assert ost == status[i]
         if len(ot) == count[i] and onfev == nfev[i]:
             same_steps += 1
             m = count[i]
-            assert np.max(np.abs(y[:m, :, i].T - oy) / (1 + np.abs(oy))) < 1e-8, f"track {i}"
+            errs.append(np.max(np.abs(y[:m, :, i].T - oy) / (1 + np.abs(oy))))
         else:  # an accept / reject decision within rounding of err = 1: the end point still agrees
             assert abs(int(count[i]) - len(ot)) <= 2
             np.testing.assert_allclose(y[min(count[i], 700) - 1, :, i], oy[:, -1], rtol=1e-6, atol=1e-6)
     assert same_steps >= n - 3, f"{n - same_steps} tracks took a different step sequence"
+    errs = np.array(errs)
+    print(f"a={a}: median {np.median(errs):.1e}  p99 {np.quantile(errs, 0.99):.1e}  max {errs.max():.1e};"
+          f"  oracle (C, one host core): {n / cpu_s:.0f} tracks/s")
+    # tracks that graze the photon orbit amplify last-bit differences exponentially: budget the tail separately
+    assert np.median(errs) < 1e-9 and np.quantile(errs, 0.98) < 1e-8 and errs.max() < 1e-5
 
 
 def test_large_batch_properties():
@@ -113,10 +121,13 @@ def test_large_batch_properties():
         r, th, pt, pr, pth, pph = p[:, 1], p[:, 2], p[:, 4], p[:, 5], p[:, 6], p[:, 7]
         S = r * r + a * a * np.cos(th) ** 2; D = r * r - 2 * r + a * a; s2 = np.sin(th) ** 2
         A = (r * r + a * a) ** 2 - a * a * D * s2
-        return 0.5 * (-A / (S * D) * pt * pt - 4 * a * r / (S * D) * pt * pph + D / S * pr * pr + pth * pth / S
-                      + (D - a * a * s2) / (S * D * s2) * pph * pph)
+        terms = np.stack([-A / (S * D) * pt * pt, -4 * a * r / (S * D) * pt * pph, D / S * pr * pr, pth * pth / S,
+                          (D - a * a * s2) / (S * D * s2) * pph * pph])
+        return np.abs(terms.sum(0)) / np.abs(terms).sum(0)   # |2H| relative to the size of its terms
     mid = y[count // 2, :, idx]
-    assert np.max(np.abs(hamiltonian(mid))) < 1e-6 and np.max(np.abs(hamiltonian(last))) < 1e-4
+    h_mid, h_last = hamiltonian(mid), hamiltonian(last)
+    print(f"relative null-condition residual: mid-track max {h_mid.max():.1e}, end max {h_last.max():.1e}")
+    assert h_mid.max() < 1e-6 and h_last.max() < 1e-6
     # times strictly increase along every track
     assert np.all(np.diff(t, axis=0)[np.arange(MP - 1)[:, None] < (count - 1)[None, :]] > 0)
     # grouping: a permuted batch gives bit-identical tracks
