@@ -242,6 +242,31 @@ def synthetic_background(height, width, seed=0):
     return rng.integers(0, 256, size=(height, width, 3), dtype=np.uint8).astype(np.float32) / 255.0
 
 
+def write_png_rgba8(path, rgba, level=1):
+    """Write an (H, W, 4) uint8 array as a PNG (8-bit RGBA, filter 0, one IDAT) with zlib alone.
+    mpimg.imsave (image_lens.py:510 of the reference) spends its time converting float RGB to RGBA8 and
+    deflating at level 6; here the GPU epilogue already produced the RGBA8 bytes (same truncation,
+    bit-exact) and level 1 is enough for a render that is written once.  Decodes to the same pixels."""
+    import struct
+    import zlib
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    if rgba.ndim != 3 or rgba.shape[2] != 4:
+        raise ValueError("rgba must be (H, W, 4) uint8")
+    h, w = rgba.shape[:2]
+    raw = np.empty((h, 1 + 4 * w), dtype=np.uint8)
+    raw[:, 0] = 0                       # filter type None on every scanline
+    raw[:, 1:] = rgba.reshape(h, 4 * w)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(raw.tobytes(), level)))
+        f.write(chunk(b"IEND", b""))
+
+
 def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_fov_deg=40.0,
          image_path="image.jpg", output_path="lensed_image.png", synthetic=None, staged=False,
          integrator=None, precision=None, schedule=None):
@@ -275,6 +300,7 @@ def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_f
              "inside FOV" if abs(bh_y) <= np.tan(fov[1] / 2) and abs(bh_x) <= np.tan(fov[0] / 2) else "outside FOV")
     print(f"BH screen offset: psi_y={np.degrees(psi[0]):.4f} deg, psi_x={np.degrees(psi[1]):.4f} deg ({where})")
 
+    rgba8 = None
     if staged:
         print("Building per-pixel " + ("alpha" if metric.is_spherically_symmetric else "(alpha, theta)") + " lookup...")
         t0 = perf_counter()
@@ -292,13 +318,17 @@ def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_f
     else:
         print("Fused GPU render (pixel -> ray -> colour)...")
         t0 = perf_counter()
-        out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=False, want=("rgb",))
+        out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=False, want=("rgb", "rgba"))
         timings["render"] = perf_counter() - t0
         timings["gpu_integrate_ms"] = out["stats"]["integrate_ms"]
         lensed, total, traced = out["rgb"], out["stats"]["rays"], out["stats"]["rays"]
+        rgba8 = out["rgba"] if lensed.ndim == 3 else None
 
     t0 = perf_counter()
-    mpimg.imsave(output_path, lensed)
+    if rgba8 is not None and str(output_path).lower().endswith(".png"):
+        write_png_rgba8(output_path, rgba8)   # the epilogue kernel's RGBA8 == imsave's conversion of `lensed`
+    else:
+        mpimg.imsave(output_path, lensed)
     timings["save_image"] = perf_counter() - t0
     timings["total"] = perf_counter() - t_total
     print_benchmark_summary((height, width), alpha_crit, total, traced, timings)

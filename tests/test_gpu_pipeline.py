@@ -118,7 +118,12 @@ def test_cli_main_runs_end_to_end(tmp_path, capsys):
     text = capsys.readouterr().out
     assert img.shape == (64, 96, 3) and out.exists()
     assert "Metric: Kerr (M=1.0, a=0.9)" in text and "Benchmark summary" in text and "total rays: 6,144" in text
-    staged = image_lens.main(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), output_path=str(out), staged=True)
+    # the fused path writes the GPU's RGBA8 with its own PNG encoder: same pixels as the reference's imsave call
+    import matplotlib.image as mpimg
+    ref_png = tmp_path / "imsave.png"
+    mpimg.imsave(str(ref_png), img)
+    np.testing.assert_array_equal(mpimg.imread(str(out)), mpimg.imread(str(ref_png)))
+    staged =image_lens.main(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), output_path=str(out), staged=True)
     # staged mode applies the reference's top/bottom mirror, the fused default does not: compare the top half
     np.testing.assert_array_equal(staged[:32], img[:32])
 

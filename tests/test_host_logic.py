@@ -105,3 +105,25 @@ def test_kerr_8d_flow_matches_reference(scalars):
     got = K.geodesic_equations(0.0, scalars["kerr_ic8"])
     np.testing.assert_allclose(got, scalars["kerr_rhs8"], rtol=1e-9, atol=1e-15)
     assert K.geodesic_equations(0.0, [0, K.r_plus, 1.0, 0, -1, 0, 0, 1]) == [0.0] * 8
+
+
+def test_png_writer_decodes_to_the_pixels_imsave_writes(tmp_path):
+    """write_png_rgba8 (fast path for the GPU's RGBA8) against the reference's save call, mpimg.imsave of the
+    float image (image_lens.py:510): both files must decode to identical pixels."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.image as mpimg
+    import image_lens
+    rng = np.random.default_rng(4)
+    rgb = rng.random((37, 53, 3), dtype=np.float32)
+    rgb[0, 0] = (0.0, 1.0, 0.999999)
+    rgba = np.empty((37, 53, 4), dtype=np.uint8)
+    rgba[..., :3] = (rgb * 255).astype(np.uint8)      # matplotlib's own float -> uint8 rule
+    rgba[..., 3] = 255
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    mpimg.imsave(a, rgb)
+    image_lens.write_png_rgba8(b, rgba)
+    ia, ib = mpimg.imread(a), mpimg.imread(b)
+    assert ia.shape == ib.shape == (37, 53, 4) and np.array_equal(ia, ib)
+    with pytest.raises(ValueError):
+        image_lens.write_png_rgba8(b, rgba[..., :3])
