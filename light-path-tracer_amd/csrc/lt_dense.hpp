@@ -32,7 +32,7 @@ struct DenseConsts {
 // (2 Sigma H = Delta p_r^2 + p_theta^2 + D^2 / sin^2 - P^2 / Delta, D = L - a E sin^2, P = E (r^2 + a^2) - a L)
 // with the energy E = -p_t a state variable, and the exact gradient: the 2H terms are kept, so the function
 // equals the reference's for any state, on shell or not.
-__device__ __forceinline__ void rhs8(const DenseConsts &k, const double *y, double *d)
+__device__ __forceinline__ void rhs8_sc(const DenseConsts &k, const double *y, double s, double c, double *d)
 {
     const double r = y[1], E = -y[4], pr = y[5], pth = y[6], L = y[7];
     if (r <= k.r_zero) {
@@ -40,13 +40,13 @@ __device__ __forceinline__ void rhs8(const DenseConsts &k, const double *y, doub
         for (int i = 0; i < 8; ++i) d[i] = 0.0;
         return;
     }
-    double s, c;
-    M<double>::sincos(y[2], s, c);
     double s2 = s * s;
     if (k.floor_sin2 && s2 < 1e-15) s2 = 1e-15;
     const double r2 = r * r, ra = r2 + k.a2;
     const double Sigma = r2 + k.a2 * c * c, Delta = ra - 2.0 * k.M * r;
-    const double iS = 1.0 / Sigma, iD = 1.0 / Delta, is2 = 1.0 / s2;
+    // one division for the three reciprocals (each float64 division is ~12 instructions around a quarter-rate v_rcp_f64)
+    const double SD = Sigma * Delta, t = 1.0 / (SD * s2);
+    const double iS = (Delta * s2) * t, iD = (Sigma * s2) * t, is2 = SD * t;
     const double P = E * ra - k.a * L, D = L - k.a * E * s2;
     const double PD = P * iD, Ds = D * is2;
     const double F = Delta * pr * pr + pth * pth + D * Ds - P * PD; // 2 Sigma H
@@ -64,6 +64,27 @@ __device__ __forceinline__ void rhs8(const DenseConsts &k, const double *y, doub
     d[6] = -0.5 * (Fth + H2 * k.a2 * sc2) * iS;
     d[7] = 0.0;
 }
+
+__device__ __forceinline__ void rhs8(const DenseConsts &k, const double *y, double *d)
+{
+    double s, c;
+    M<double>::sincos(y[2], s, c);
+    rhs8_sc(k, y, s, c, d);
+}
+
+// right-hand side at a stage state whose polar angle is th0 + (y[2] - th0) with (s0, c0) = sincos(th0): the
+// stages of a step sit within a fraction of a radian of its base point, so sin / cos come from a rotation of
+// the base pair (sincos_shift; full evaluation per lane beyond 0.25 rad) instead of a fresh argument reduction
+__device__ __forceinline__ void rhs8_near(const DenseConsts &k, const double *y, double th0, double s0, double c0,
+                                          double *d, double &s, double &c)
+{
+    sincos_shift(th0, s0, c0, y[2] - th0, s, c);
+    rhs8_sc(k, y, s, c, d);
+}
+
+// err^(-1/5) of the step controller as exp2(-0.2 log2(err)): half the instructions of the general pow(), relative
+// error ~1e-15 -- it scales the next step size, where solve_ivp's own libm differs from ours by as much
+__device__ __forceinline__ double pow_m02(double x) { return exp2(-0.2 * log2(x)); }
 
 __device__ __forceinline__ double rms8(const double *x)
 {
@@ -163,7 +184,9 @@ __global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const dou
         ++n_pts;
     };
     push(t, y);
-    rhs8(k, y, f); ++nfev;
+    double s0, c0, ss, cc, sn, cn; // sin / cos of y[2], carried with f (FSAL); stage values; candidate next state's
+    M<double>::sincos(y[2], s0, c0);
+    rhs8_sc(k, y, s0, c0, f); ++nfev;
     double h_abs;
     { // initial step (Hairer, Norsett, Wanner II.4), error-estimator order 4
         double v[8], sc[8], y1[8], f1[8];
@@ -199,23 +222,23 @@ __global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const dou
             h_abs = fabs(h);
 #pragma unroll
             for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * h;
-            rhs8(k, tmp, k2);
+            rhs8_near(k, tmp, y[2], s0, c0, k2, ss, cc);
 #pragma unroll
             for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * h;
-            rhs8(k, tmp, k3);
+            rhs8_near(k, tmp, y[2], s0, c0, k3, ss, cc);
 #pragma unroll
             for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * h;
-            rhs8(k, tmp, k4);
+            rhs8_near(k, tmp, y[2], s0, c0, k4, ss, cc);
 #pragma unroll
             for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * h;
-            rhs8(k, tmp, k5);
+            rhs8_near(k, tmp, y[2], s0, c0, k5, ss, cc);
 #pragma unroll
             for (int c = 0; c < 8; ++c)
                 tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * h;
-            rhs8(k, tmp, k6);
+            rhs8_near(k, tmp, y[2], s0, c0, k6, ss, cc);
 #pragma unroll
             for (int c = 0; c < 8; ++c) yn[c] = y[c] + h * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
-            rhs8(k, yn, k7);
+            rhs8_near(k, yn, y[2], s0, c0, k7, sn, cn);
             nfev += 6;
             double e[8];
 #pragma unroll
@@ -225,12 +248,12 @@ __global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const dou
             }
             const double err = rms8(e);
             if (err < 1.0) {
-                double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow(err, -0.2));
+                double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow_m02(err));
                 if (rejected) factor = fmin(1.0, factor);
                 h_abs *= factor;
                 break;
             }
-            h_abs *= fmax(0.2, 0.9 * pow(err, -0.2)); // a NaN norm shrinks by 0.2, as in scipy (max(0.2, nan))
+            h_abs *= fmax(0.2, 0.9 * pow_m02(err)); // a NaN norm shrinks by 0.2, as in scipy (max(0.2, nan))
             rejected = true;
         }
         if (failed) { status = attempts > k.max_attempts ? -2 : -1; break; }
@@ -267,6 +290,7 @@ __global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const dou
         t = t_new;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { y[c] = yn[c]; f[c] = k7[c]; }
+        s0 = sn; c0 = cn;
         push(t, y);
     }
     o.count[i] = n_pts;
