@@ -19,6 +19,12 @@
 
 namespace lt {
 
+// true if the predicate holds in any active lane: the wave-uniform test behind every fast path.  The builtin
+// reads the compare's lane mask directly (HIP's __ballot(int) first materialises the bool in a VGPR and
+// compares it again: two extra VALU instructions per test).
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+
 // ---------------------------------------------------------------------------------------
 // scalar math wrappers
 // ---------------------------------------------------------------------------------------
@@ -225,12 +231,15 @@ __device__ __forceinline__ RayConsts<T> make_ray_consts(const KerrConsts<T> &k, 
 // hardware reciprocal of their product.  At or inside r_cut the reference returns zeros
 // (metrics.py:228-231): every output carries the factor 1/Sigma, so masking that one factor (and
 // evaluating at max(r, r_cut) so nothing overflows) does it.
-template <typename T>
+//
+// CHECKED = false leaves the r <= r_cut handling out: for callers that know, or verify afterwards, that
+// the radius is outside (kerr_rk4_step_fast below).  Arithmetic otherwise identical.
+template <typename T, bool CHECKED = true>
 __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T s, T c, T pr, T pth,
                                             T &dr, T &dth, T &dph, T &dpr, T &dpth)
 {
-    bool inside = r_in <= k.r_cut;
-    const bool any_inside = __ballot(inside) != 0ull; // almost never: only a stage of the last steps before capture
+    bool inside = CHECKED && r_in <= k.r_cut;
+    const bool any_inside = CHECKED && wave_any(inside); // almost never: only a stage of the last steps before capture
     T r = r_in;
     if (__builtin_expect(any_inside, 0)) r = inside ? k.r_cut : r_in;
     T s2 = M<T>::sin2_floor(s);
@@ -278,15 +287,15 @@ __device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts
 // the step's base state by h * (a small angular velocity), so the 25-instruction argument reduction +
 // polynomials shrink to an 11-instruction rotation.  The wave falls back to the full evaluation in the
 // rare step where some lane's |d| exceeds 0.25 rad (wave-uniform branch).
-template <typename T>
+template <typename T, bool CHECKED = true>
 __device__ __forceinline__ void sincos_shift(T th0, T s0, T c0, T d, T &s, T &c)
 {
     T sd, cd;
     M<T>::sincos_small(d, sd, cd);
     s = M<T>::fma(s0, cd, c0 * sd);
     c = M<T>::fma(c0, cd, -(s0 * sd));
-    bool big = M<T>::abs(d) > T(0.25);
-    if (__builtin_expect(__ballot(big) != 0ull, 0)) {
+    bool big = CHECKED && M<T>::abs(d) > T(0.25);
+    if (__builtin_expect(CHECKED && wave_any(big), 0)) {
         // which formula a lane uses depends on ITS angle only, never on its neighbours: results stay
         // bit-identical however rays are grouped into waves (direct vs queue schedule, partitions)
         T sf, cf;
@@ -302,30 +311,46 @@ template <typename T> struct State5 {
 
 // Classic RK4 step, metrics.py:306-323 (phi does not enter the right-hand side, so the stage states
 // carry only r, theta, p_r, p_theta).
-template <typename T>
-__device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const RayConsts<T> &rc,
-                                                   const State5<T> &y, T h)
+//
+// CHECKED = true: every stage handles r <= r_cut and a stage angle offset beyond 0.25 rad on the spot (one
+// wave-uniform branch each: seven per step).  CHECKED = false: no such branches; the step reports the
+// smallest stage radius and the largest stage offset instead, so that the caller can tell afterwards
+// whether either case occurred (then the unchecked result is wrong for that lane and must be replaced by
+// the checked one) -- one test per step instead of seven, for the same results.
+template <typename T, bool CHECKED>
+__device__ __forceinline__ State5<T> kerr_rk4_step_impl(const KerrConsts<T> &k, const RayConsts<T> &rc,
+                                                        const State5<T> &y, T h, T &min_r, T &max_d)
 {
     T k_r, k_th, k_ph, k_pr, k_pth;
     T a_r, a_th, a_ph, a_pr, a_pth; // running k1 + 2 k2 + 2 k3 + k4
     T s0, c0, s, c;
     M<T>::sincos(y.th, s0, c0); // the only full sincos of the step; stages rotate it (sincos_shift)
-    kerr_rhs_sc(k, rc, y.r, s0, c0, y.pr, y.pth, k_r, k_th, k_ph, k_pr, k_pth);
+    kerr_rhs_sc<T, CHECKED>(k, rc, y.r, s0, c0, y.pr, y.pth, k_r, k_th, k_ph, k_pr, k_pth);
     a_r = k_r; a_th = k_th; a_ph = k_ph; a_pr = k_pr; a_pth = k_pth;
     T hh = T(0.5) * h;
     T t_r = M<T>::fma(hh, k_r, y.r), t_pr = M<T>::fma(hh, k_pr, y.pr), t_pth = M<T>::fma(hh, k_pth, y.pth);
-    sincos_shift(y.th, s0, c0, hh * k_th, s, c);
-    kerr_rhs_sc(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    T d2 = hh * k_th;
+    T r2 = t_r;
+    sincos_shift<T, CHECKED>(y.th, s0, c0, d2, s, c);
+    kerr_rhs_sc<T, CHECKED>(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
     a_r = M<T>::fma(T(2), k_r, a_r); a_th = M<T>::fma(T(2), k_th, a_th); a_ph = M<T>::fma(T(2), k_ph, a_ph);
     a_pr = M<T>::fma(T(2), k_pr, a_pr); a_pth = M<T>::fma(T(2), k_pth, a_pth);
     t_r = M<T>::fma(hh, k_r, y.r); t_pr = M<T>::fma(hh, k_pr, y.pr); t_pth = M<T>::fma(hh, k_pth, y.pth);
-    sincos_shift(y.th, s0, c0, hh * k_th, s, c);
-    kerr_rhs_sc(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    T d3 = hh * k_th;
+    T r3 = t_r;
+    sincos_shift<T, CHECKED>(y.th, s0, c0, d3, s, c);
+    kerr_rhs_sc<T, CHECKED>(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
     a_r = M<T>::fma(T(2), k_r, a_r); a_th = M<T>::fma(T(2), k_th, a_th); a_ph = M<T>::fma(T(2), k_ph, a_ph);
     a_pr = M<T>::fma(T(2), k_pr, a_pr); a_pth = M<T>::fma(T(2), k_pth, a_pth);
     t_r = M<T>::fma(h, k_r, y.r); t_pr = M<T>::fma(h, k_pr, y.pr); t_pth = M<T>::fma(h, k_pth, y.pth);
-    sincos_shift(y.th, s0, c0, h * k_th, s, c);
-    kerr_rhs_sc(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    T d4 = h * k_th;
+    sincos_shift<T, CHECKED>(y.th, s0, c0, d4, s, c);
+    kerr_rhs_sc<T, CHECKED>(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    if (!CHECKED) {
+        // (a NaN stage value is ignored by min / max; it makes the step's result non-finite in either variant)
+        min_r = M<T>::min(M<T>::min(r2, r3), t_r);
+        max_d = M<T>::max(M<T>::max(M<T>::abs(d2), M<T>::abs(d3)), M<T>::abs(d4));
+    }
     T h6 = h * T(1.0 / 6.0);
     State5<T> o;
     o.r = M<T>::fma(h6, a_r + k_r, y.r);
@@ -334,6 +359,22 @@ __device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const
     o.pr = M<T>::fma(h6, a_pr + k_pr, y.pr);
     o.pth = M<T>::fma(h6, a_pth + k_pth, y.pth);
     return o;
+}
+
+template <typename T>
+__device__ __forceinline__ State5<T> kerr_rk4_step(const KerrConsts<T> &k, const RayConsts<T> &rc,
+                                                   const State5<T> &y, T h)
+{
+    T unused_r, unused_d;
+    return kerr_rk4_step_impl<T, true>(k, rc, y, h, unused_r, unused_d);
+}
+
+// The branch-free variant; valid for a lane iff min_r > k.r_cut and max_d <= 0.25 (kerr_rk4_step_ok).
+template <typename T>
+__device__ __forceinline__ State5<T> kerr_rk4_step_fast(const KerrConsts<T> &k, const RayConsts<T> &rc,
+                                                        const State5<T> &y, T h, T &min_r, T &max_d)
+{
+    return kerr_rk4_step_impl<T, false>(k, rc, y, h, min_r, max_d);
 }
 
 // Step-size rule of the reference's fixed-step RK4 tracer (metrics.py:597-611): h_base, capped in
@@ -345,7 +386,7 @@ template <typename T>
 __device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, const RayConsts<T> &rc, T r, T remaining)
 {
     T h = rc.hb;
-    if (__ballot(r < k.rc4) != 0ull) {
+    if (wave_any(r < k.rc4)) {
         T c4 = rc.refine ? T(0.20) : T(0.25), c2 = rc.refine ? T(0.08) : T(0.10), c12 = rc.refine ? T(0.03) : T(0.05);
         h = (r < k.rc4) ? M<T>::min(h, c4) : h;
         h = (r < k.rc2) ? M<T>::min(h, c2) : h;
@@ -371,6 +412,53 @@ template <typename T> __device__ __forceinline__ void ray_start(const KerrConsts
     s.lam = T(0); s.h_retry = T(0); s.steps = 0;
 }
 
+// A streak of ordinary far-field steps.  While EVERY active lane of the wave is outside 4 r_capture with
+// nothing to retry, the tracer's loop body (metrics.py:596-655) reduces to: h = min(h_base, remaining), one
+// RK4 step, accept.  This loop does exactly that with ONE wave-uniform branch per step -- the predicate
+// `good` says that the step was ordinary and that the lane is still in the far field afterwards -- where
+// the general iteration below (kerr_rk4_advance) spends four.  Bulk waves take ~60 % of their steps here;
+// for a wave hosting one of the few very long rays, alone on its SIMD at the end of the launch, a taken
+// branch costs ~80 cycles, so this is what sets the length of the launch's tail.
+// A lane for which `good` fails keeps its state (the general iteration redoes that step); lanes for which
+// it holds keep the step -- lanes are independent, they need not stay in lockstep.  Same arithmetic as the
+// general iteration (kerr_rk4_step_fast, same h), so which of the two paths took a step does not matter.
+// Returns the number of loop iterations (wave-uniform).
+template <typename T>
+__device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, const RayConsts<T> &rc, RayState<T> &s,
+                                                    uint32_t max_steps)
+{
+    if (wave_any(!((s.y.r >= k.rc4) & (s.h_retry == T(0))))) return 0;
+    uint32_t done = 0;
+    State5<T> n;
+    T h;
+    bool good;
+    // (predicates are combined with & and |, not && and ||: short-circuit evaluation would turn them into branches)
+    auto attempt = [&]() {
+        T remaining = k.lambda_max - s.lam;
+        h = M<T>::min(rc.hb, remaining);
+        T min_r, max_d;
+        n = kerr_rk4_step_fast(k, rc, s.y, h, min_r, max_d);
+        T mag = M<T>::abs(n.r) + M<T>::abs(n.th) + M<T>::abs(n.ph) + M<T>::abs(n.pr) + M<T>::abs(n.pth);
+        good = (remaining > T(0)) & M<T>::finite(mag) & (n.r >= k.rc4) & (n.r < k.r_escape) & (min_r > k.r_cut) &
+               !(max_d > T(0.25));
+        ++done;
+    };
+    auto accept = [&]() {
+        s.y = n;
+        s.lam += h;
+        ++s.steps;
+    };
+    // rotated so that one iteration = accept the previous attempt + make the next one, closed by a single
+    // conditional backward branch
+    attempt();
+    while (!wave_any(!good) & (done < max_steps)) {
+        accept();
+        attempt();
+    }
+    if (good) accept();
+    return done;
+}
+
 // One iteration of the reference's fixed-step RK4 tracer (metrics.py:596-655): choose h, take an RK4
 // step, halve-and-retry on a non-finite result, stop on the capture / escape crossing with the
 // reference's linear interpolation.  Returns EV_RUNNING or the terminating event.  Both schedules of
@@ -385,22 +473,35 @@ __device__ __forceinline__ int kerr_rk4_advance(const KerrConsts<T> &k, const Ra
 {
     T remaining = k.lambda_max - s.lam;
     T h = kerr_rk4_h(k, rc, s.y.r, remaining);
-    if (__builtin_expect(__ballot(s.h_retry > T(0)) != 0ull, 0)) h = (s.h_retry > T(0)) ? s.h_retry : h;
+    if (__builtin_expect(wave_any(s.h_retry > T(0)), 0)) h = (s.h_retry > T(0)) ? s.h_retry : h;
     bool live = remaining > T(0); // then h > 0 too: every candidate for h is positive
     // (a lane whose range is exhausted still computes the step -- at most once per ray -- and drops it)
-    State5<T> n = kerr_rk4_step(k, rc, s.y, h);
+    T min_r, max_d;
+    State5<T> n = kerr_rk4_step_fast(k, rc, s.y, h, min_r, max_d);
+    // the branch-free step is wrong for a lane one of whose stages sat at r <= r_cut or turned by more than
+    // 0.25 rad (both rare): such a lane takes the checked step below
+    // (& and |, not && and ||: short-circuit evaluation would turn these predicates into branches)
+    bool redo = (min_r <= k.r_cut) | (max_d > T(0.25));
     // all five components finite <=> the sum of their magnitudes is (NaN and inf both propagate)
     T mag = M<T>::abs(n.r) + M<T>::abs(n.th) + M<T>::abs(n.ph) + M<T>::abs(n.pr) + M<T>::abs(n.pth);
-    bool ok = M<T>::finite(mag) && n.r > T(0);
+    bool ok = M<T>::finite(mag) & (n.r > T(0));
     // strictly between the capture and the escape radius: neither crossing test of the reference fires
-    bool between = n.r > k.r_capture && n.r < k.r_escape;
-    bool plain = live && ok && between;
-    if (__builtin_expect(__ballot(!plain) == 0ull, 1)) {
+    bool between = (n.r > k.r_capture) & (n.r < k.r_escape);
+    bool plain = live & ok & between & !redo;
+    if (__builtin_expect(!wave_any(!plain), 1)) {
         s.y = n;
         s.lam += h;
         s.h_retry = T(0);
         ++s.steps;
         return EV_RUNNING;
+    }
+    if (wave_any(redo)) {
+        // per lane: only a flagged lane takes the checked result, so nobody's numbers depend on a neighbour
+        State5<T> e = kerr_rk4_step(k, rc, s.y, h);
+        n.r = redo ? e.r : n.r; n.th = redo ? e.th : n.th; n.ph = redo ? e.ph : n.ph;
+        n.pr = redo ? e.pr : n.pr; n.pth = redo ? e.pth : n.pth;
+        mag = M<T>::abs(n.r) + M<T>::abs(n.th) + M<T>::abs(n.ph) + M<T>::abs(n.pr) + M<T>::abs(n.pth);
+        ok = M<T>::finite(mag) && n.r > T(0);
     }
     if (!live) return EV_MAXRANGE;
     ++s.steps;

@@ -23,6 +23,11 @@ template <typename T> struct Rk4 {
     {
         return kerr_rk4_advance(k, rc, s);
     }
+    // up to max_steps ordinary far-field steps for the whole wave at one branch per step; returns how many
+    static __device__ __forceinline__ uint32_t streak(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, uint32_t max_steps)
+    {
+        return kerr_rk4_streak(k, rc, s, max_steps);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -72,6 +77,8 @@ template <typename T> struct Dp45 {
         s.h = M<T>::max(T(1), T(0.01) * k.r_obs);           // metrics.py:449
         s.steps = 0;
     }
+
+    static __device__ __forceinline__ uint32_t streak(const KerrConsts<T> &, const RayConsts<T> &, State &, uint32_t) { return 0; }
 
     // One attempt of the loop body metrics.py:454-564.
     static __device__ __forceinline__ int advance(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s)
