@@ -399,7 +399,6 @@ __global__ void __launch_bounds__(256) k_kerr_queue(KerrConsts<T> k_in, const ty
             continue;
         }
         if (have) {
-            Integ::streak(k, rc, st, 8u); // short: idle lanes wait for their refill meanwhile
             int ev = Integ::advance(k, rc, st);
             if (ev != EV_RUNNING) {
                 store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
