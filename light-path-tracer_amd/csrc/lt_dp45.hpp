@@ -15,6 +15,7 @@ namespace lt {
 template <typename T> struct Rk4 {
     using State = RayState<T>;
     static constexpr int EVALS_FIXED = 0, EVALS_PER_STEP = 4;
+    static constexpr int MIN_WAVES_PER_SIMD = 1; // no constraint: float32 fits 5, float64 2
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &, State &s, T p_r, T p_th)
     {
         ray_start(k, s, p_r, p_th);
@@ -59,14 +60,7 @@ template <typename T> struct Dp45State {
 template <typename T> struct Dp45 {
     using State = Dp45State<T>;
     static constexpr int EVALS_FIXED = 1, EVALS_PER_STEP = 6;
-
-    // right-hand side at stage state y, whose polar angle is th0 + dth with (s0, c0) = sincos(th0)
-    static __device__ __forceinline__ void rhs5(const KerrConsts<T> &k, const RayConsts<T> &rc, const T *y, T th0, T s0,
-                                                T c0, T dth, T *d, T &s, T &c)
-    {
-        sincos_shift(th0, s0, c0, dth, s, c);
-        kerr_rhs_sc(k, rc, y[0], s, c, y[3], y[4], d[0], d[1], d[2], d[3], d[4]);
-    }
+    static constexpr int MIN_WAVES_PER_SIMD = 2; // hold the register allocation at 256 (it sits just above)
 
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, T p_r, T p_th)
     {
@@ -80,8 +74,23 @@ template <typename T> struct Dp45 {
 
     static __device__ __forceinline__ uint32_t streak(const KerrConsts<T> &, const RayConsts<T> &, State &, uint32_t) { return 0; }
 
-    // One attempt of the loop body metrics.py:454-564.
-    static __device__ __forceinline__ int advance(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s)
+    // right-hand side at stage state y, whose polar angle is th0 + dth with (s0, c0) = sincos(th0).
+    // CHECKED = false: without the in-line r <= r_cut and |dth| > 0.25 handling (see attempt()).
+    template <bool CHECKED>
+    static __device__ __forceinline__ void rhs5(const KerrConsts<T> &k, const RayConsts<T> &rc, const T *y, T th0, T s0,
+                                                T c0, T dth, T *d, T &s, T &c)
+    {
+        sincos_shift<T, CHECKED>(th0, s0, c0, dth, s, c);
+        kerr_rhs_sc<T, CHECKED>(k, rc, y[0], s, c, y[3], y[4], d[0], d[1], d[2], d[3], d[4]);
+    }
+
+    // The arithmetic of one step attempt: six stages, the candidate next state nxt with its derivative k7 (FSAL)
+    // and trigonometry (sn, cn), and the squared error norm.  The unchecked variant has no branches; it reports
+    // the smallest stage radius and the largest stage angle offset so that the caller can tell whether the
+    // checked variant (fourteen wave-uniform tests per attempt) was needed for this lane.
+    template <bool CHECKED>
+    static __device__ __forceinline__ void attempt(const KerrConsts<T> &k, const RayConsts<T> &rc, const State &s, T h,
+                                                   T *nxt, T *k7, T &sn, T &cn, T &err_sq, T &min_r, T &max_d)
     {
         const T A21 = T(1.0 / 5.0), A31 = T(3.0 / 40.0), A32 = T(9.0 / 40.0), A41 = T(44.0 / 45.0), A42 = T(-56.0 / 15.0),
                 A43 = T(32.0 / 9.0), A51 = T(19372.0 / 6561.0), A52 = T(-25360.0 / 2187.0), A53 = T(64448.0 / 6561.0),
@@ -90,45 +99,44 @@ template <typename T> struct Dp45 {
         const T B1 = T(35.0 / 384.0), B3 = T(500.0 / 1113.0), B4 = T(125.0 / 192.0), B5 = T(-2187.0 / 6784.0), B6 = T(11.0 / 84.0);
         const T E1 = T(71.0 / 57600.0), E3 = T(-71.0 / 16695.0), E4 = T(71.0 / 1920.0), E5 = T(-17253.0 / 339200.0),
                 E6 = T(22.0 / 525.0), E7 = T(-1.0 / 40.0);
-        const T h_min = T(1e-12);
-        if (s.steps >= 200000u || !(s.lam < k.lambda_max)) return EV_MAXRANGE;
-        T remaining = k.lambda_max - s.lam;
-        if (s.h > remaining) s.h = remaining;
-        if (!(s.h > T(0))) return EV_MAXRANGE;
-        ++s.steps;
-        const T h = s.h;
         const T y[5] = {s.y.r, s.y.th, s.y.ph, s.y.pr, s.y.pth};
-        T k2[5], k3[5], k4[5], k5[5], k6[5], k7[5], tmp[5], nxt[5];
+        T k2[5], k3[5], k4[5], k5[5], k6[5], tmp[5];
         const T *k1 = s.k1;
-        T ss, cc, sn, cn; // stage sin / cos; (sn, cn) belong to the candidate next state
+        T ss, cc;
         const T th0 = y[1], s0 = s.s0, c0 = s.c0;
+        T d2, d3, d4, d5, d6, d7, r2, r3, r4, r5, r6;
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * A21 * k1[i];
-        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k2, ss, cc);
+        d2 = tmp[1] - th0; r2 = tmp[0];
+        rhs5<CHECKED>(k, rc, tmp, th0, s0, c0, d2, k2, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A31 * k1[i] + A32 * k2[i]);
-        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k3, ss, cc);
+        d3 = tmp[1] - th0; r3 = tmp[0];
+        rhs5<CHECKED>(k, rc, tmp, th0, s0, c0, d3, k3, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A41 * k1[i] + A42 * k2[i] + A43 * k3[i]);
-        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k4, ss, cc);
+        d4 = tmp[1] - th0; r4 = tmp[0];
+        rhs5<CHECKED>(k, rc, tmp, th0, s0, c0, d4, k4, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) tmp[i] = y[i] + h * (A51 * k1[i] + A52 * k2[i] + A53 * k3[i] + A54 * k4[i]);
-        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k5, ss, cc);
+        d5 = tmp[1] - th0; r5 = tmp[0];
+        rhs5<CHECKED>(k, rc, tmp, th0, s0, c0, d5, k5, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             tmp[i] = y[i] + h * (A61 * k1[i] + A62 * k2[i] + A63 * k3[i] + A64 * k4[i] + A65 * k5[i]);
-        rhs5(k, rc, tmp, th0, s0, c0, tmp[1] - th0, k6, ss, cc);
+        d6 = tmp[1] - th0; r6 = tmp[0];
+        rhs5<CHECKED>(k, rc, tmp, th0, s0, c0, d6, k6, ss, cc);
 #pragma unroll
         for (int i = 0; i < 5; ++i) nxt[i] = y[i] + h * (B1 * k1[i] + B3 * k3[i] + B4 * k4[i] + B5 * k5[i] + B6 * k6[i]);
-        rhs5(k, rc, nxt, th0, s0, c0, nxt[1] - th0, k7, sn, cn);
-
-        T mag = M<T>::abs(nxt[0]) + M<T>::abs(nxt[1]) + M<T>::abs(nxt[2]) + M<T>::abs(nxt[3]) + M<T>::abs(nxt[4]);
-        if (!(M<T>::finite(mag) && nxt[0] > T(0))) { // metrics.py:500-504
-            s.h *= T(0.25);
-            return s.h < h_min ? EV_INVALID : EV_RUNNING;
+        d7 = nxt[1] - th0;
+        rhs5<CHECKED>(k, rc, nxt, th0, s0, c0, d7, k7, sn, cn);
+        if (!CHECKED) { // (min / max ignore a NaN stage value; it makes nxt non-finite in either variant)
+            min_r = M<T>::min(M<T>::min(M<T>::min(r2, r3), M<T>::min(r4, r5)), M<T>::min(r6, nxt[0]));
+            max_d = M<T>::max(M<T>::max(M<T>::max(M<T>::abs(d2), M<T>::abs(d3)), M<T>::max(M<T>::abs(d4), M<T>::abs(d5))),
+                              M<T>::max(M<T>::abs(d6), M<T>::abs(d7)));
         }
         const T atol = rc.refine ? T(1e-10) : T(1e-8), rtol = rc.refine ? T(1e-8) : T(1e-6); // metrics.py:431-432
-        T err_sq = T(0);
+        err_sq = T(0);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             T ei = h * (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
@@ -137,6 +145,38 @@ template <typename T> struct Dp45 {
             // and scales h; a float64 division is ~25 instructions, five of them per attempt
             T q = ei * (T)M<float>::rcp_pos((float)sc);
             err_sq += q * q;
+        }
+    }
+
+    // One attempt of the loop body metrics.py:454-564.
+    static __device__ __forceinline__ int advance(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s)
+    {
+        const T h_min = T(1e-12);
+        if (s.steps >= 200000u || !(s.lam < k.lambda_max)) return EV_MAXRANGE;
+        T remaining = k.lambda_max - s.lam;
+        if (s.h > remaining) s.h = remaining;
+        if (!(s.h > T(0))) return EV_MAXRANGE;
+        ++s.steps;
+        const T h = s.h;
+        const T y[5] = {s.y.r, s.y.th, s.y.ph, s.y.pr, s.y.pth};
+        T nxt[5], k7[5], sn, cn, err_sq, min_r, max_d;
+        attempt<false>(k, rc, s, h, nxt, k7, sn, cn, err_sq, min_r, max_d);
+        // one test per attempt instead of fourteen: a lane one of whose stages sat at r <= r_cut (the last attempts
+        // before capture) or turned by more than 0.25 rad takes the checked arithmetic -- that lane only, so
+        // nobody's numbers depend on a neighbour
+        const bool redo = (min_r <= k.r_cut) | (max_d > T(0.25));
+        if (__builtin_expect(wave_any(redo), 0)) {
+            T nx2[5], k72[5], sn2, cn2, e2, u1, u2;
+            attempt<true>(k, rc, s, h, nx2, k72, sn2, cn2, e2, u1, u2);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { nxt[i] = redo ? nx2[i] : nxt[i]; k7[i] = redo ? k72[i] : k7[i]; }
+            sn = redo ? sn2 : sn; cn = redo ? cn2 : cn; err_sq = redo ? e2 : err_sq;
+        }
+
+        T mag = M<T>::abs(nxt[0]) + M<T>::abs(nxt[1]) + M<T>::abs(nxt[2]) + M<T>::abs(nxt[3]) + M<T>::abs(nxt[4]);
+        if (!(M<T>::finite(mag) && nxt[0] > T(0))) { // metrics.py:500-504
+            s.h *= T(0.25);
+            return s.h < h_min ? EV_INVALID : EV_RUNNING;
         }
         // err_norm = sqrt(err_sq / 5); err_norm^(-0.2) = (err_sq / 5)^(-0.1)
         const T grow = T(0.9) * (T)pow_minus_tenth((float)(err_sq * T(0.2)));

@@ -296,7 +296,7 @@ __device__ __forceinline__ void store_fin(typename Vec4<T>::type *fin0, typename
 
 // Direct schedule: one work-item per ray, a wavefront = one 8x8 tile.
 template <typename T, typename Integ>
-__global__ void __launch_bounds__(256) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
+__global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
                                                          uint32_t long_iters, uint4 *__restrict__ stamps)
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) k_kerr_direct(KerrConsts<T> k_in, const t
 // up to ~50x the mean step count) raises its issue priority so that the serial chain of that one
 // ray is not time-sliced 8 ways against bulk work.
 template <typename T, typename Integ>
-__global__ void __launch_bounds__(256) k_kerr_queue(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
+__global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                         typename Vec4<T>::type *__restrict__ fin0,
                                                         typename Vec4<T>::type *__restrict__ fin1, uint32_t n_q,
                                                         uint32_t *__restrict__ head, uint32_t chunk,
