@@ -23,3 +23,8 @@ order = np.argsort(-dur)[:8]
 for i in order:
     print(f"  long wave {i}: start {t0[i]/100:.1f} us dur {dur[i]/100:.1f} us steps {steps[i]} ticks/step {dur[i]/max(steps[i],1):.2f} xcc {xcc[i]}")
 print("waves per xcc:", np.bincount(xcc, minlength=8))
+# where the longest waves ran: HW_ID fields (gfx9 layout: wave [3:0], simd [5:4], cu [11:8], sh [12], se [15:13])
+print("placement of the longest waves (xcc, se, sh, cu, simd, slot):")
+for i in order:
+    h = int(hw[i])
+    print(f"  wave {i}: xcc {xcc[i]} se {(h >> 13) & 7} sh {(h >> 12) & 1} cu {(h >> 8) & 15} simd {(h >> 4) & 3} slot {h & 15}  steps {steps[i]}")
