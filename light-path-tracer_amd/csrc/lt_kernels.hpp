@@ -613,7 +613,7 @@ __device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int
 // Grid-stride over the partition's pixels in row-major order: every output array is written fully
 // coalesced whatever order the integrate kernel finished the rays in.
 template <typename T>
-__global__ void __launch_bounds__(256) k_epilogue_frame(CamConsts c, MetricConsts m,
+__global__ void __launch_bounds__(256, 3) k_epilogue_frame(CamConsts c, MetricConsts m,
                                                         const typename Vec4<T>::type *__restrict__ fin0,
                                                         const typename Vec4<T>::type *__restrict__ fin1, FrameOut o)
 {
