@@ -244,6 +244,25 @@ static int make_metric(const lt_metric *m, double r_obs, double theta_obs, doubl
     mc->phi_h = h_schw;
     mc->evals_fixed = 0;
     mc->evals_per_step = 4;
+    { // the observer-only part of metrics.py:148-218, in its operation order (K1 used to redo this per ray)
+        double r = r_obs, a = mc->a, M_ = mc->M;
+        double sin_th = sin(theta_obs), cos_th = cos(theta_obs);
+        double sin_th_sq = sin_th * sin_th;
+        if (sin_th_sq < 1e-15) sin_th_sq = 1e-15;
+        double Sigma = r * r + a * a * cos_th * cos_th;
+        double Delta = r * r - 2.0 * M_ * r + a * a;
+        mc->obs_ok = Delta > 0.0 && Sigma > 0.0;
+        mc->obs_sin_th = sin_th; mc->obs_cos2 = cos_th * cos_th; mc->obs_sin2 = sin_th_sq;
+        mc->obs_sqrt_Sigma = mc->obs_ok ? sqrt(Sigma) : 0.0;
+        mc->obs_sqrt_Delta = mc->obs_ok ? sqrt(Delta) : 1.0;
+        double A_val = (r * r + a * a) * (r * r + a * a) - a * a * Delta * sin_th_sq;
+        double SD = mc->obs_ok ? Sigma * Delta : 1.0;
+        mc->obs_g_tt = -A_val / SD;
+        mc->obs_g_tphi = -2.0 * M_ * a * r / SD;
+        mc->obs_g_rr = mc->obs_ok ? Delta / Sigma : 1.0;
+        mc->obs_g_thth = mc->obs_ok ? 1.0 / Sigma : 0.0;
+        mc->obs_g_phiphi = (Delta - a * a * sin_th_sq) / (SD * sin_th_sq);
+    }
     return LT_OK;
 }
 

@@ -48,6 +48,12 @@ struct MetricConsts { // float64 view of the metric for K1 / K3
     double M, a, r_obs, theta_obs, r_plus, r_capture, R_S;
     double phi_h; // Schwarzschild step h_max (to rebuild phi_f)
     int evals_fixed, evals_per_step; // RHS evaluations: RK4 0 + 4/step, DP45 1 + 6/attempt
+    // What metrics.py:148-218 computes from the observer alone (not from the ray), evaluated ONCE on the host
+    // in the reference's operation order instead of once per ray in float64 on the GPU: sin / cos of the
+    // observer's polar angle, Sigma, Delta, their roots and the inverse metric at the observer.
+    int obs_ok; // Delta > 0 and Sigma > 0 (metrics.py:160-161)
+    double obs_sin_th, obs_cos2, obs_sin2, obs_sqrt_Sigma, obs_sqrt_Delta, obs_g_tt, obs_g_tphi, obs_g_rr, obs_g_thth,
+        obs_g_phiphi;
 };
 
 __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
@@ -157,32 +163,21 @@ __device__ __forceinline__ void pixel_angles(const CamConsts &c, int ix, int gro
 __device__ __forceinline__ bool kerr_initial_momenta(const MetricConsts &m, double alpha, double theta,
                                                      double &p_r, double &p_theta, double &p_phi)
 {
-    double r = m.r_obs, a = m.a, M_ = m.M;
-    double sin_th = sin(m.theta_obs), cos_th = cos(m.theta_obs);
-    double sin_th_sq = sin_th * sin_th;
-    if (sin_th_sq < 1e-15) sin_th_sq = 1e-15;
-    double Sigma = r * r + a * a * cos_th * cos_th;
-    double Delta = r * r - 2.0 * M_ * r + a * a;
+    double r = m.r_obs, a = m.a;
     p_r = p_theta = p_phi = 0.0;
-    if (Delta <= 0.0 || Sigma <= 0.0) return false;
+    if (!m.obs_ok) return false;
     double sin_alpha = sin(alpha), sin_screen, cos_screen;
     sincos(theta, &sin_screen, &cos_screen);
-    double rho = r * sin_alpha * sqrt(Sigma) / sqrt(Delta);
+    double rho = r * sin_alpha * m.obs_sqrt_Sigma / m.obs_sqrt_Delta;
     double alpha_screen = -rho * sin_screen, beta_screen = -rho * cos_screen;
-    double xi = -alpha_screen * sin_th;
-    double eta = beta_screen * beta_screen + cos_th * cos_th * (alpha_screen * alpha_screen - a * a);
+    double xi = -alpha_screen * m.obs_sin_th;
+    double eta = beta_screen * beta_screen + m.obs_cos2 * (alpha_screen * alpha_screen - a * a);
     double L = xi, Q = eta;
-    double Theta = Q - cos_th * cos_th * (L * L / sin_th_sq - a * a);
+    double Theta = Q - m.obs_cos2 * (L * L / m.obs_sin2 - a * a);
     if (Theta < 0.0) Theta = 0.0;
     p_theta = (cos_screen > 0.0 ? -1.0 : 1.0) * sqrt(Theta);
-    double A_val = (r * r + a * a) * (r * r + a * a) - a * a * Delta * sin_th_sq;
-    double g_tt = -A_val / (Sigma * Delta);
-    double g_tphi = -2.0 * M_ * a * r / (Sigma * Delta);
-    double g_rr = Delta / Sigma;
-    double g_thth = 1.0 / Sigma;
-    double g_phiphi = (Delta - a * a * sin_th_sq) / (Sigma * Delta * sin_th_sq);
-    double other = g_tt + 2.0 * g_tphi * (-1.0) * L + g_thth * p_theta * p_theta + g_phiphi * L * L;
-    double p_r_sq = -other / g_rr;
+    double other = m.obs_g_tt + 2.0 * m.obs_g_tphi * (-1.0) * L + m.obs_g_thth * p_theta * p_theta + m.obs_g_phiphi * L * L;
+    double p_r_sq = -other / m.obs_g_rr;
     if (p_r_sq < 0.0) p_r_sq = 0.0;
     p_r = -sqrt(p_r_sq);
     p_phi = L;
