@@ -244,8 +244,9 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     if (__builtin_expect(any_inside, 0)) r = inside ? k.r_cut : r_in;
     T s2 = M<T>::sin2_floor(s);
     T r2 = r * r;
-    T Sigma = M<T>::fma(k.a2 * c, c, r2);
-    T Delta = M<T>::fma(-k.two_M, r, r2) + k.a2;
+    T ra = r2 + k.a2;
+    T Sigma = M<T>::fma(-k.a2, s2, ra);          // r^2 + a^2 cos^2 as r^2 + a^2 - a^2 sin^2 (the 1e-15 floor is far below an ulp)
+    T Delta = M<T>::fma(-k.two_M, r, ra);
     T SD = Sigma * Delta;
     T t = M<T>::rcp_pos(SD * s2); // > 0: r >= r_cut > r_plus so Delta > 0, Sigma > 0, s2 >= 1e-15
     T iS = (Delta * s2) * t;
@@ -260,18 +261,18 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     dr = Delta * iSpr;
     dth = pth * iS;
     dph = iS * M<T>::fma(k.a, q, Lis2 - k.a);
-    T two_r = r + r;
-    T Fr = M<T>::fma(two_r - k.two_M, M<T>::fma(q, q, pr2), T(-2) * two_r * q);
-    T mhiS = T(-0.5) * iS;
-    // (dropping the 2H terms -- zero on a null geodesic -- would save 8 instructions per evaluation, but the
-    // reference's RK4 solution drifts off-shell at h = 1 and they matter: measured median |d final_alpha|
-    // 5.6e-6 without them against 4.4e-7 with them, and p99 1e-1 against 2e-5)
+    // (dropping the 2H terms -- zero on a null geodesic -- would save instructions, but the reference's RK4
+    // solution drifts off-shell at h = 1 and they matter: measured median |d final_alpha| 5.6e-6 without them
+    // against 4.4e-7 with them, and p99 1e-1 against 2e-5)
     T W = M<T>::fma(rc.L, Lis2, M<T>::fma(k.a2, s2, rc.c_W));
     T F = M<T>::fma(Delta, pr2, M<T>::fma(pth, pth, M<T>::fma(-P, q, W)));
     T H2 = F * iS;
-    dpr = mhiS * M<T>::fma(-H2, two_r, Fr);
-    // F_theta = 2 s c (a^2 - L^2/s^4),  Sigma_theta = -2 a^2 s c
-    dpth = (T(2) * mhiS) * (s * c) * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2));
+    // dp_r = -(F_r - 2H Sigma_r) / (2 Sigma) with F_r = (2r - 2M)(q^2 + p_r^2) - 4 r q, Sigma_r = 2r; the factor
+    // 1/2 goes into the bracket:  -(1/Sigma) [ (r - M)(q^2 + p_r^2) - r (2q + 2H) ]
+    T rt = r * M<T>::fma(T(2), q, H2);
+    dpr = -iS * M<T>::fma(r - k.M, M<T>::fma(q, q, pr2), -rt);
+    // dp_theta likewise: F_theta = 2 s c (a^2 - L^2/s^4), Sigma_theta = -2 a^2 s c:  -(1/Sigma) s c [a^2 (1 + 2H) - (L/s^2)^2]
+    dpth = -iS * ((s * c) * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2)));
 }
 
 template <typename T>
