@@ -56,12 +56,9 @@ __device__ __forceinline__ void rhs8_sc(const DenseConsts &k, const double *y, d
     d[2] = pth * iS;
     d[3] = (Ds + k.a * PD) * iS;
     d[4] = 0.0;
-    const double Dr = 2.0 * r - 2.0 * k.M;
-    const double Fr = Dr * (pr * pr + PD * PD) - 4.0 * r * E * PD;
-    d[5] = -0.5 * (Fr - H2 * 2.0 * r) * iS;
-    const double sc2 = 2.0 * s * c;
-    const double Fth = -sc2 * Ds * (2.0 * k.a * E + Ds);
-    d[6] = -0.5 * (Fth + H2 * k.a2 * sc2) * iS;
+    // -(F_r - 2H Sigma_r) / (2 Sigma) and -(F_theta - 2H Sigma_theta) / (2 Sigma) with the factor 1/2 folded in
+    d[5] = -iS * ((r - k.M) * (pr * pr + PD * PD) - r * (2.0 * E * PD + H2));
+    d[6] = iS * (s * c) * (Ds * (2.0 * k.a * E + Ds) - H2 * k.a2);
     d[7] = 0.0;
 }
 
