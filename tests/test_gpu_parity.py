@@ -166,6 +166,8 @@ FRAMES = [
     ("kerr", 0.9, 50.0, 256, 256, (0.0, 0.0), False),
     ("kerr", 0.9, 100.0, 160, 120, (0.05, 0.3), False),
     ("kerr", 0.99, 50.0, 129, 97, (0.0, 0.0), True),      # odd sizes + reference tb symmetry (Q1)
+    ("kerr", -0.7, 50.0, 192, 160, (0.0, 0.0), False),    # spin pointing the other way (|a| <= M is all the reference asks)
+    ("kerr", 0.3, 30.0, 136, 200, (-0.04, 0.02), False),  # slow spin, close observer, tall frame
 ]
 
 
@@ -190,8 +192,11 @@ def test_frame_matches_oracle(kind, a, r_obs, W, H, psi, tb, precision):
     else:
         # float32 budget: median 5e-6, p99 5e-5 rad (measured there at a = 0.9); the
         # near-extremal a = 0.99 frame amplifies rounding about twice as much: p99 1e-4 rad, stated here
-        p99_budget = 1e-4 if a > 0.95 else 5e-5
+        # and from r_obs = 30 M the strongly lensed band around the critical curve fills more than 1 % of this
+        # frame, so its p99 sits in that band (measured 2.6e-4); the p90 is then held to the p99 budget instead
+        p99_budget = 1e-4 if a > 0.95 else (5e-4 if r_obs < 40 else 5e-5)
         assert np.median(d) <= 5e-6 and np.quantile(d, 0.99) <= p99_budget
+        assert np.quantile(d, 0.90) <= 5e-5
     assert np.array_equal(np.isnan(out["fa"]), ~esc_g)
     wd = out["winding"][~flips] != ref["winding"][~flips]
     assert wd.sum() <= max(2, int(budget * n))
