@@ -168,6 +168,10 @@ FRAMES = [
     ("kerr", 0.99, 50.0, 129, 97, (0.0, 0.0), True),      # odd sizes + reference tb symmetry (Q1)
     ("kerr", -0.7, 50.0, 192, 160, (0.0, 0.0), False),    # spin pointing the other way (|a| <= M is all the reference asks)
     ("kerr", 0.3, 30.0, 136, 200, (-0.04, 0.02), False),  # slow spin, close observer, tall frame
+    ("kerr", 1.0, 50.0, 96, 96, (0.0, 0.0), False),       # extremal: r_plus = M, Delta has a double root there
+    ("kerr", 0.9, 50.0, 120, 80, (0.0, 1.0), False),      # black hole outside the field of view (57 deg off axis)
+    ("kerr", 0.9, 50.0, 96, 64, (0.2, 2.6), False),       # black hole behind the camera: in_front is false
+    ("schwarzschild", 0.0, 12.0, 100, 100, (0.0, 0.0), False),  # observer at 12 M: the shadow fills a third of the frame
 ]
 
 
@@ -198,8 +202,12 @@ def test_frame_matches_oracle(kind, a, r_obs, W, H, psi, tb, precision):
         assert np.median(d) <= 5e-6 and np.quantile(d, 0.99) <= p99_budget
         assert np.quantile(d, 0.90) <= 5e-5
     assert np.array_equal(np.isnan(out["fa"]), ~esc_g)
-    wd = out["winding"][~flips] != ref["winding"][~flips]
-    assert wd.sum() <= max(2, int(budget * n))
+    wd = (out["winding"] != ref["winding"]) & ~flips
+    assert (wd & both).sum() <= max(2, int(budget * n))
+    # captured rays: their half-orbit count is whatever phi reached at the capture radius (it never colours a
+    # pixel).  At |a| = M the horizon is a double root of Delta and float32 loses r^2 - 2Mr + a^2 to cancellation
+    # there, so this count alone gets a looser budget in the extremal frame
+    assert (wd & ~both).sum() <= (max(2, int(budget * n)) if abs(a) < 0.999 or precision == 64 else int(0.01 * n))
     st = out["stats"]
     traced = ref["traced"]
     assert st["rays"] == traced
