@@ -479,3 +479,35 @@ def test_c_abi_error_codes():
     o = ltrace.default_opts(n_parts=8, part=7, row_block=16)
     empty = ltrace.render(_cam(32, 40, 50.0), met, o, want=("status", "rgba"))
     assert empty["status"].shape == (0, 32) and empty["stats"]["rays"] == 0
+
+
+DP45_FRAMES = [
+    # a, r_obs, W, H, psi, tb
+    (0.9, 50.0, 160, 160, (0.0, 0.0), True),      # the reference's own default path: DP45 with its top/bottom mirror
+    (-0.7, 50.0, 144, 112, (0.03, -0.06), False),
+    (1.0, 40.0, 96, 96, (0.0, 0.0), False),
+    (0.5, 200.0, 128, 96, (0.0, 0.0), False),     # far observer: the shadow is a handful of pixels
+]
+
+
+@pytest.mark.parametrize("a,r_obs,W,H,psi,tb", DP45_FRAMES)
+def test_dp45_frame_matches_oracle(a, r_obs, W, H, psi, tb):
+    """The reference's production integrator (metrics.py:419-567) through the fused frame path against the
+    oracle's DP45 on the same camera.  Budget as for the per-ray fixtures: the float32 step controller moves a
+    few accept / reject decisions, each by the integrator's own tolerance; final_alpha is stored in float32."""
+    cam = _cam(W, H, r_obs, psi=psi)
+    met = ltrace.Metric(1, 0, 1.0, a)
+    bg = _background(H, W, seed=3)
+    out = ltrace.render(cam, met, ltrace.default_opts(integrator="dp45", precision=64, tb_symmetry=int(tb)), background=bg)
+    ref = oracle.lookup("kerr", 1.0, a, r_obs, H, W, cam.hfov, cam.vfov, psi=psi, integrator="dp45", tb_symmetry=tb)
+    n = W * H
+    esc_g, esc_r = out["status"] == 1, ref["status"] == 1
+    assert (esc_g != esc_r).sum() <= max(1, int(2e-4 * n))
+    both = esc_g & esc_r
+    d = np.abs(out["fa"][both].astype(np.float64) - ref["fa"][both])
+    assert np.median(d) <= 2.4e-7 and np.quantile(d, 0.99) <= 5e-6, (np.median(d), np.quantile(d, 0.99))
+    assert (out["winding"][both] != ref["winding"][both]).sum() <= max(2, int(2e-4 * n))
+    img = oracle.render(bg, out["fa"], out["winding"], cam.hfov, cam.vfov, psi=psi)
+    assert np.array_equal(out["rgb"], img)
+    img_ref = oracle.render(bg, ref["fa"], ref["winding"], cam.hfov, cam.vfov, psi=psi)
+    assert np.all(out["rgb"] == img_ref, axis=-1).mean() >= 0.995
