@@ -394,6 +394,9 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
             continue;
         }
         if (have) {
+            // a far-field streak only while nothing is waiting for it to end: every lane busy (fewer idle lanes than
+            // the refill threshold) or the queue drained
+            if (n_idle < refill_min || drained) Integ::streak(k, rc, st, 16u);
             int ev = Integ::advance(k, rc, st);
             if (ev != EV_RUNNING) {
                 store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
