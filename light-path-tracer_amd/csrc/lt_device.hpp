@@ -430,33 +430,45 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
 {
     if (wave_any(!((s.y.r >= k.rc4) & (s.h_retry == T(0))))) return 0;
     uint32_t done = 0;
-    State5<T> n;
-    T h;
-    bool good;
+    // One attempt: from state `from` at affine parameter lam into `to`; true if it was an ordinary far-field step.
     // (predicates are combined with & and |, not && and ||: short-circuit evaluation would turn them into branches)
-    auto attempt = [&]() {
-        T remaining = k.lambda_max - s.lam;
+    auto attempt = [&](const State5<T> &from, T lam, State5<T> &to, T &h) -> bool {
+        T remaining = k.lambda_max - lam;
         h = M<T>::min(rc.hb, remaining);
         T min_r, max_d;
-        n = kerr_rk4_step_fast(k, rc, s.y, h, min_r, max_d);
-        T mag = M<T>::abs(n.r) + M<T>::abs(n.th) + M<T>::abs(n.ph) + M<T>::abs(n.pr) + M<T>::abs(n.pth);
-        good = (remaining > T(0)) & M<T>::finite(mag) & (n.r >= k.rc4) & (n.r < k.r_escape) & (min_r > k.r_cut) &
-               !(max_d > T(0.25));
+        to = kerr_rk4_step_fast(k, rc, from, h, min_r, max_d);
+        T mag = M<T>::abs(to.r) + M<T>::abs(to.th) + M<T>::abs(to.ph) + M<T>::abs(to.pr) + M<T>::abs(to.pth);
         ++done;
+        return (remaining > T(0)) & M<T>::finite(mag) & (to.r >= k.rc4) & (to.r < k.r_escape) & (min_r > k.r_cut) &
+               !(max_d > T(0.25));
     };
-    auto accept = [&]() {
-        s.y = n;
+    // The state ping-pongs between two register sets (A = s.y, B) so that accepting an attempt costs no copies:
+    // the loop body is two attempts, A -> B and B -> A, each followed by the one wave-uniform test.  On leaving,
+    // a lane keeps the attempted state if its own predicate held, its previous state otherwise.
+    State5<T> b;
+    T h;
+    for (;;) {
+        bool good = attempt(s.y, s.lam, b, h);
+        if (wave_any(!good) | (done >= max_steps)) {
+            s.y.r = good ? b.r : s.y.r; s.y.th = good ? b.th : s.y.th; s.y.ph = good ? b.ph : s.y.ph;
+            s.y.pr = good ? b.pr : s.y.pr; s.y.pth = good ? b.pth : s.y.pth;
+            s.lam = good ? s.lam + h : s.lam;
+            s.steps += good ? 1u : 0u;
+            break;
+        }
         s.lam += h;
         ++s.steps;
-    };
-    // rotated so that one iteration = accept the previous attempt + make the next one, closed by a single
-    // conditional backward branch
-    attempt();
-    while (!wave_any(!good) & (done < max_steps)) {
-        accept();
-        attempt();
+        good = attempt(b, s.lam, s.y, h);
+        if (wave_any(!good) | (done >= max_steps)) {
+            s.y.r = good ? s.y.r : b.r; s.y.th = good ? s.y.th : b.th; s.y.ph = good ? s.y.ph : b.ph;
+            s.y.pr = good ? s.y.pr : b.pr; s.y.pth = good ? s.y.pth : b.pth;
+            s.lam = good ? s.lam + h : s.lam;
+            s.steps += good ? 1u : 0u;
+            break;
+        }
+        s.lam += h;
+        ++s.steps;
     }
-    if (good) accept();
     return done;
 }
 
