@@ -177,7 +177,8 @@ def main():
     if rank == 0:
         # HBM bytes per launch of the integrate kernel: PMC counters cannot be read from inside this
         # process, so the figure comes from the committed rocprofv3 pass for this exact workload
-        workload = f"{args.metric}_a{args.a}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
+        spin = args.a if args.metric == "kerr" else 0.0
+        workload = f"{args.metric}_a{spin}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
@@ -194,7 +195,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-            "config": {"workload": f"{args.metric}_a{args.a}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
+            "config": {"workload": workload
                                    + ("_lensed_background" if args.background else ""),
                        "rays_per_frame": rays_per_frame, "schedule": args.schedule,
                        "row_partition": f"block-cyclic {rb} rows x {world}", "gather": "rccl" if world > 1 else "none",
