@@ -147,6 +147,16 @@ __device__ __forceinline__ int64_t pixel_to_q(const CamConsts &c, int ix, int lr
 
 // (alpha, theta) of a pixel: image_lens.py:141-152 (alpha, rounded to float32 -- quirk Q2) and
 // image_lens.py:197-208 (theta).
+__device__ __forceinline__ double pixel_alpha(const CamConsts &c, int ix, int grow)
+{
+    double x_cam = ((double)ix - c.half_W) / c.fx;
+    double y_cam = ((double)grow - c.half_H) / c.fy;
+    double denom = sqrt(1.0 + x_cam * x_cam + y_cam * y_cam);
+    double cos_alpha = ((x_cam * c.d[0]) + (y_cam * c.d[1]) + c.d[2]) / denom;
+    cos_alpha = fmin(fmax(cos_alpha, -1.0), 1.0);
+    return (double)(float)acos(cos_alpha);
+}
+
 __device__ __forceinline__ void pixel_angles(const CamConsts &c, int ix, int grow, double &alpha, double &theta)
 {
     double x_cam = ((double)ix - c.half_W) / c.fx;
@@ -218,8 +228,9 @@ __global__ void __launch_bounds__(256) k_prologue_camera(CamConsts c, MetricCons
     q_to_pixel(c, q, ix, lrow);
     if (ix >= c.W || lrow >= c.trace_rows) { store_ic<T>(ic, q, 0, 0, 0, FLAG_PAD); return; }
     int grow = local_to_global_row(c, lrow);
-    double alpha, theta;
-    pixel_angles(c, ix, grow, alpha, theta);
+    double alpha, theta = 0.0;
+    if (m.kind == 0) alpha = pixel_alpha(c, ix, grow); // a spherically symmetric metric never looks at theta
+    else pixel_angles(c, ix, grow, alpha, theta);
     int flags = 0;
     if (c.refine_on) {
         double x_cam = ((double)ix - c.half_W) / c.fx;
