@@ -511,3 +511,35 @@ def test_dp45_frame_matches_oracle(a, r_obs, W, H, psi, tb):
     assert np.array_equal(out["rgb"], img)
     img_ref = oracle.render(bg, ref["fa"], ref["winding"], cam.hfov, cam.vfov, psi=psi)
     assert np.all(out["rgb"] == img_ref, axis=-1).mean() >= 0.995
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes_do_not_depend_on_grouping(seed):
+    """Seeded random cameras and metrics: whatever the scene, a ray's result must not depend on which rays share its
+    wavefront -- the direct schedule, the queue schedule and a block-cyclic partition reassembled from its parts
+    agree bit for bit (fixed-step float32 and float64, and the adaptive integrator)."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(17, 200)), int(rng.integers(17, 160))
+    r_obs = float(rng.choice([8.0, 20.0, 50.0, 120.0, 300.0]))
+    a = float(rng.choice([-1.0, -0.6, 0.0, 0.3, 0.9, 0.998, 1.0]))
+    psi = (float(rng.normal(0, 0.08)), float(rng.normal(0, 0.12)))
+    hfov = float(np.radians(rng.uniform(15, 70)))
+    cam = ltrace.Camera(W, H, hfov, 2 * np.arctan(np.tan(hfov / 2) * H / W), psi[0], psi[1], r_obs, np.pi / 2)
+    met = ltrace.Metric(1, 0, 1.0, a)
+    integ, prec = [("rk4", 32), ("rk4", 64), ("dp45", 64)][seed % 3]
+    keys = ("fa", "winding", "status", "steps")
+    whole = ltrace.render(cam, met, ltrace.default_opts(integrator=integ, precision=prec, schedule="direct"), want=keys)
+    queue = ltrace.render(cam, met, ltrace.default_opts(integrator=integ, precision=prec, schedule="queue"), want=keys)
+    for k in keys:
+        assert np.array_equal(whole[k], queue[k], equal_nan=True), (k, "queue", W, H, a, r_obs, integ, prec)
+    n_parts, rb = int(rng.integers(2, 6)), int(rng.choice([8, 16, 24]))
+    acc = {k: np.zeros_like(whole[k]) for k in keys}
+    for p in range(n_parts):
+        o = ltrace.default_opts(integrator=integ, precision=prec, n_parts=n_parts, part=p, row_block=rb)
+        part = ltrace.render(cam, met, o, want=keys)
+        rows = ltrace.global_rows(H, rb, n_parts, p)
+        for k in keys:
+            acc[k][rows] = part[k]
+    for k in keys:
+        assert np.array_equal(acc[k], whole[k], equal_nan=True), (k, "partitions", n_parts, rb, W, H, a, r_obs, integ, prec)
+    assert np.isfinite(whole["fa"]).sum() == (whole["status"] == 1).sum()
