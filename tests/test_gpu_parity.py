@@ -543,3 +543,28 @@ def test_random_scenes_do_not_depend_on_grouping(seed):
     for k in keys:
         assert np.array_equal(acc[k], whole[k], equal_nan=True), (k, "partitions", n_parts, rb, W, H, a, r_obs, integ, prec)
     assert np.isfinite(whole["fa"]).sum() == (whole["status"] == 1).sum()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_match_oracle_in_float64(seed):
+    """Seeded random cameras / metrics in float64 against the oracle: same algorithm, so the frames agree up to the
+    chaotic rays on the critical curve (budget as in test_frame_matches_oracle)."""
+    rng = np.random.default_rng(2000 + seed)
+    W, H = int(rng.integers(40, 150)), int(rng.integers(40, 120))
+    r_obs = float(rng.choice([10.0, 25.0, 50.0, 150.0]))
+    a = float(rng.choice([-0.95, -0.3, 0.5, 0.9, 0.999]))
+    psi = (float(rng.normal(0, 0.05)), float(rng.normal(0, 0.08)))
+    hfov = float(np.radians(rng.uniform(20, 60)))
+    vfov = float(2 * np.arctan(np.tan(hfov / 2) * H / W))
+    cam = ltrace.Camera(W, H, hfov, vfov, psi[0], psi[1], r_obs, np.pi / 2)
+    integ = "dp45" if seed % 2 else "rk4"
+    out = ltrace.render(cam, ltrace.Metric(1, 0, 1.0, a), ltrace.default_opts(integrator=integ, precision=64),
+                        want=("fa", "winding", "status"))
+    ref = oracle.lookup("kerr", 1.0, a, r_obs, H, W, hfov, vfov, psi=psi, integrator=integ)
+    n = W * H
+    esc_g, esc_r = out["status"] == 1, ref["status"] == 1
+    assert (esc_g != esc_r).sum() <= max(1, int(2e-4 * n)), (W, H, a, r_obs, integ)
+    both = esc_g & esc_r
+    d = np.abs(out["fa"][both].astype(np.float64) - ref["fa"][both])
+    assert np.quantile(d, 0.99) <= (2e-7 if integ == "rk4" else 5e-6), (np.quantile(d, 0.99), W, H, a, r_obs, integ)
+    assert (out["winding"][both] != ref["winding"][both]).sum() <= max(2, int(2e-4 * n))
