@@ -127,3 +127,44 @@ def test_png_writer_decodes_to_the_pixels_imsave_writes(tmp_path):
     assert ia.shape == ib.shape == (37, 53, 4) and np.array_equal(ia, ib)
     with pytest.raises(ValueError):
         image_lens.write_png_rgba8(b, rgba[..., :3])
+
+
+def test_row_partition_properties_hold_for_any_frame():
+    """Property test of lt_local_rows / lt_global_row: for any height, block size and partition count the parts
+    tile range(height) exactly once, each part's rows ascend, and blocks go round-robin."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(1, 5000), st.integers(1, 64), st.integers(1, 16))
+    def check(height, row_block, n_parts):
+        seen = np.zeros(height, dtype=np.int32)
+        for p in range(n_parts):
+            rows = ltrace.global_rows(height, row_block, n_parts, p)
+            assert rows.size == ltrace.local_rows(height, row_block, n_parts, p)
+            if rows.size:
+                assert np.all(np.diff(rows) > 0) and rows[0] >= 0 and rows[-1] < height
+                assert np.all((rows // row_block) % n_parts == p)
+            seen[rows] += 1
+        assert np.all(seen == 1)
+
+    check()
+    assert ltrace.local_rows(10, 16, 4, 4) == -1 and ltrace.local_rows(0, 16, 1, 0) == -1   # out-of-range part, empty frame
+
+
+def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
+    """Compile a probe against include/ltrace.h with gcc and compare sizeof / offsetof with the ctypes mirrors."""
+    import subprocess
+    src = tmp_path / "probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "ltrace.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(lt_camera), sizeof(lt_metric), sizeof(lt_opts),\n'
+        '  sizeof(lt_stats), sizeof(lt_dense_opts), offsetof(lt_opts, stream), offsetof(lt_dense_opts, max_points),\n'
+        '  offsetof(lt_dense_opts, stream)); return 0; }\n')
+    exe = tmp_path / "probe"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(ltrace.Camera), ctypes.sizeof(ltrace.Metric), ctypes.sizeof(ltrace.Opts), ctypes.sizeof(ltrace.Stats),
+            ctypes.sizeof(ltrace.DenseOpts), ltrace.Opts.stream.offset, ltrace.DenseOpts.max_points.offset,
+            ltrace.DenseOpts.stream.offset]
+    assert got == want
