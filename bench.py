@@ -2,7 +2,7 @@
 """bench.py -- north-star benchmark: Mrays/s of a 4096x4096 Kerr (a = 0.9) shadow render,
 fixed-step RK4 in float32, on N MI355X of one node.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N --steps K --warmup W          (starts its own N ranks when N > 1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,14 +12,30 @@ stream), then the RGBA8 framebuffer is gathered to rank 0 over RCCL and un-permu
 The frame is fixed as N grows, so scaling is "strong".  Everything the timed region reads is
 already resident in HBM; no per-ray input exists (pixel -> ray happens in the prologue kernel).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the integrate kernel against the FP32 VALU
-peak with the reference's as-written flop counts; `cpu_baseline` is the oracle
-(CPU port of the reference algorithm, float64, OpenMP) timed on this host on a strided
-subsample of the same frame.
+Ranks.  `--gpus N` means N processes, one per GPU.  Started under torchrun (RANK / WORLD_SIZE set)
+this file is one of them and WORLD_SIZE must equal N.  Started plainly with N > 1 it is the
+launcher: BEFORE anything touches the GPU it checks that the node has N devices (exit 2 otherwise)
+and starts N copies of itself as child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+set, waits for them and exits with their worst code.  It never replaces a process that has
+initialised the GPU.  A rank whose process group does not have N members exits non-zero.
+
+Rank 0 prints ONE JSON line.
+  roofline      the integrate kernel against the FP32 VALU ISSUE peak, from the work it executed:
+                wave-instructions per launch (rocprofv3 SQ_INSTS_VALU for this workload and this
+                build, profiles/valu_counts.json, scaled by the loop iterations the kernel counted
+                in THIS run) x 128 lane-flops per issue slot / the kernel's HIP-event time.  One
+                VALU instruction occupies a SIMD for 2 cycles (MI355X_MICROARCH.md), so the peak is
+                1024 SIMDs x 2.4 GHz / 2 = 1.2288e12 wave-instructions/s = 157.3 TFLOP/s of FMAs and
+                frac <= 1 by construction.  The reference's as-written flop count, which
+                the kernel does not execute, is reported beside it as `algorithmic_as_written`.
+  cpu_baseline  the oracle (CPU port of the reference algorithm, float64, OpenMP) compiled
+                -O3 -march=native on this host, on a strided subsample of the same frame.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,13 +43,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "light-path-tracer_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import ltrace  # noqa: E402
-import sharding  # noqa: E402
 
 # As-written flop counts of the reference
 F_RK4_STEP = 4 * 188 + 80     # 832 per RK4 step   (metrics.py:221-323)
@@ -43,9 +52,12 @@ F_SCHW_STEP = 54
 F_SCHW_FIXED = 45
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_FP64_VALU_TFLOPS = 78.6   # float64 vector rate = half the float32 one
+N_SIMD = 256 * 4               # CUs x SIMDs
+NOMINAL_CLOCK_HZ = 2.4e9
+CYCLES_PER_VALU = {32: 2.0, 64: 4.0}   # issue cycles of one wave64 FMA-class instruction on a SIMD-32
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -59,49 +71,224 @@ def parse():
     ap.add_argument("--integrator", choices=["rk4", "dp45"], default="rk4")
     ap.add_argument("--row-block", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (end-to-end host-pointer frame, longest-ray chain)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--background", action="store_true", help="image_lens workload: lens a synthetic background")
-    return ap.parse_args()
+    ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; tests use gloo)")
+    ap.add_argument("--stub-render", action="store_true",
+                    help="CPU rehearsal of the launcher / gather path: no GPU, rows filled by a formula (tests only)")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------
+# launcher
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run: no GPU call is made in this process (device_count() does not initialise one)."""
+    if not args.stub_render:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s); refusing to report a "
+                  f"{args.gpus}-GPU number from fewer devices", file=sys.stderr)
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    deadline = time.time() + float(os.environ.get("LT_BENCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            rc = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            rc = 124
+        if rc != 0:
+            worst = worst or rc
+            for q in procs:               # one rank failed: do not leave the others waiting in a collective
+                if q.poll() is None:
+                    q.kill()
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------
+# untimed extras
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(args, fov):
-    """Oracle (CPU port of the reference's RK4 tracer, float64, all cores) on a strided subsample of
-    the benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame
-    of the same camera."""
+    """Oracle (CPU port of the reference's tracer, float64, all cores), perf build, on a strided subsample of
+    the benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame of the
+    same camera."""
     from oracle import oracle
     kind = args.metric
     t0 = time.perf_counter()
-    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, integrator=args.integrator)
-    dt = time.perf_counter() - t0          # calibration (includes thread spin-up)
+    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, integrator=args.integrator, perf_build=True)
+    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, integrator=args.integrator, perf_build=True)
+    dt = (time.perf_counter() - t0) / 2    # calibration (the first call compiles and spins the threads up)
     rate = 256 * 256 / dt
     stride = 2
     while stride < args.size // 256 and (args.size // stride) ** 2 / rate > args.cpu_seconds:
         stride *= 2
     n = args.size // stride
     t0 = time.perf_counter()
-    r = oracle.lookup(kind, 1.0, args.a, args.r_obs, n, n, fov, fov, integrator=args.integrator)
+    r = oracle.lookup(kind, 1.0, args.a, args.r_obs, n, n, fov, fov, integrator=args.integrator, perf_build=True)
     dt = time.perf_counter() - t0
     return {"value": round(n * n / dt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.num_threads(),
-            "kind": "port",
+            "kind": "port (perf build: gcc " + " ".join(oracle.PERF_FLAGS[:3]) + ", built on this host)",
             "sample": f"{n}x{n} rays = every {stride}th pixel (x and y) of the {args.size}x{args.size} frame, "
                       f"oracle {args.integrator} float64 + OpenMP, {dt:.1f} s",
             "mean_rhs_evals_per_ray": round(float(r["evals"].mean()), 1)}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+def end_to_end(ltrace, cam, met, args, np):
+    """What `python image_lens.py` pays per frame: the host-pointer lt_render with an RGBA8 destination only,
+    device buffers persistent, destination pinned (ltrace.render's own arrays) or pageable (any numpy array)."""
+    o = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
+    res = {}
+    import ctypes as C
+    for name in ("pinned_dst_ms", "pageable_dst_ms"):
+        if name == "pinned_dst_ms":
+            rgba = ltrace.pinned_empty((cam.height, cam.width, 4), np.uint8)
+        else:
+            rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
+            rgba[:] = 0                                      # touch the pages: a first-touch fault is not PCIe
+        st = ltrace.Stats()
+        call = lambda: ltrace._check(ltrace.load().lt_render(C.byref(cam), C.byref(met), C.byref(o), None, 3, None, None,
+                                                             None, None, None, C.c_void_p(rgba.ctypes.data), C.byref(st)))
+        call()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            call()
+        res[name] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    res["what"] = "host-pointer lt_render, RGBA8 out only, mean of 5 frames (device time + PCIe + host copy)"
+    return res
+
+
+def longest_chain(ltrace, cam, met, args, steps_host, np):
+    """The serial chain that bounds small frames and strong scaling: the frame's longest ray traced ALONE on the chip."""
+    size = cam.width
+    iy, ix = divmod(int(np.argmax(steps_host)), size)
+    n_steps = int(steps_host[iy, ix])
+    f = (size / 2.0) / np.tan(cam.hfov / 2)
+    x, y = (ix - size / 2.0) / f, (iy - size / 2.0) / f      # image_lens.py:141-142, psi = (0, 0)
+    den = np.sqrt(1.0 + x * x + y * y)
+    alpha = float(np.float32(np.arccos(1.0 / den)))
+    theta = float(np.arctan2(x / den, y / den))
+    x_lo, x_hi = abs((0 - size / 2.0) / f), abs((size - 1 - size / 2.0) / f)
+    refine = int(abs(x) <= 0.07 * max(x_lo, x_hi))            # image_lens.py:210-214
+
+    def run(al, th, rf):
+        fa, w = np.empty(64), np.empty(64, dtype=np.int64)
+        ev = np.empty(64, dtype=np.uint32)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ltrace.trace_batch_kerr(1.0, args.a, args.r_obs, np.full(64, al), np.full(64, th), np.pi / 2,
+                                    max(5000.0, 6.0 * args.r_obs), np.full(64, rf, dtype=np.uint8), fa, w,
+                                    integrator=args.integrator, precision=args.precision, out_rhs_evals=ev)
+            best = min(best, time.perf_counter() - t0)
+        return best, int(ev[0])
+    base, _ = run(0.3, 1.0, 0)                                # a short ray: the call's fixed cost
+    t, _ = run(alpha, theta, refine)
+    alone_ms = (t - base) * 1e3
+    return {"longest_ray_steps": n_steps, "pixel": [iy, ix], "alone_ms": round(alone_ms, 3),
+            "us_per_step": round(alone_ms * 1e3 / max(n_steps, 1), 4),
+            "what": "the frame's longest ray traced alone on the chip (one wavefront): no launch of this frame, "
+                    "on any number of GPUs, ends before it does"}
+
+
+def load_profile_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def stub_main(args, world, rank):
+    """Launcher / gather rehearsal on CPU (tests): same process-group setup, FrameGather, timing and JSON
+    plumbing as the real path; rows are filled by a formula instead of a render."""
+    import torch
+    import torch.distributed as dist
+    import sharding
+    if world > 1:
+        dist.init_process_group(backend=args.backend or "gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+    size = args.size
+    fg = sharding.FrameGather(size, size, 4, torch.uint8, "cpu", args.row_block, world, rank)
+    rows = sharding.global_row_index(size, args.row_block, world, rank).to(torch.int64)
+    val = ((rows[:, None, None] * 131 + torch.arange(size)[None, :, None] * 7 + torch.arange(4)[None, None, :] * 3) % 251)
+    ok = True
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        fg.local_view().copy_(val.to(torch.uint8))
+        full = fg.gather()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        r = torch.arange(size)
+        expect = ((r[:, None, None] * 131 + torch.arange(size)[None, :, None] * 7 + torch.arange(4)[None, None, :] * 3) % 251)
+        ok = bool(torch.equal(full, expect.to(torch.uint8)))
+        print(json.dumps({"metric": "Mrays/s", "value": 0.0, "unit": "Mrays/s", "n_gpus": world, "stub": True,
+                          "rccl_world": dist.get_world_size() if world > 1 else 1, "frame_ok": ok,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 3)}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args, argv)
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus}, "
+              f"or plainly and let it start its own ranks", file=sys.stderr)
+        return 2
+    if args.stub_render:
+        return stub_main(args, world, rank)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import ltrace
+    import sharding
+
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
+        return 2
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants GPU {local_rank} but the node has {torch.cuda.device_count()}", file=sys.stderr)
+        return 2
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_world = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend=args.backend or "nccl", device_id=dev)
+        rccl_world = dist.get_world_size()
+        if rccl_world != args.gpus:
+            print(f"bench.py: the process group has {rccl_world} ranks, --gpus {args.gpus}", file=sys.stderr)
+            return 2
 
     size = args.size
     fov = float(np.radians(40.0))
@@ -126,12 +313,20 @@ def main():
     opts = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
                                row_block=rb, n_parts=world, part=rank, timing=1)
     opts.stream = stream.cuda_stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(args.steps, 1))]   # frame start / rendered / gathered
 
-    def step():
+    def step(i=None):
+        if i is not None:
+            ev[3 * i].record(stream)
         ltrace.render_dev(cam, met, opts, d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
                           d_fa=d_fa.data_ptr(), d_w=d_w.data_ptr(), d_rgba=d_rgba.data_ptr(),
                           d_stats=d_stats.data_ptr())
-        return fg.gather(stream.cuda_stream)   # N > 1: RCCL gather to rank 0 + row un-permute there
+        if i is not None:
+            ev[3 * i + 1].record(stream)
+        full = fg.gather(stream.cuda_stream)   # N > 1: RCCL gather to rank 0 + row un-permute there
+        if i is not None:
+            ev[3 * i + 2].record(stream)
+        return full
 
     def fence():
         if world > 1:
@@ -145,78 +340,147 @@ def main():
     d_stats.zero_()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     fence()
     elapsed = time.perf_counter() - t0
     tm = ltrace.timing_collect()
 
+    steps = max(args.steps, 1)
+    render_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.steps)) / steps
+    gather_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)) / steps
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     counters = d_stats.clone()
-    kern = torch.tensor([tm["prologue_ms"], tm["integrate_ms"], tm["epilogue_ms"]], dtype=torch.float64, device=dev)
-    kern_max = kern.clone()
+    mine = torch.tensor([tm["prologue_ms"] / steps, tm["integrate_ms"] / steps, tm["epilogue_ms"] / steps,
+                         render_ms, gather_ms], dtype=torch.float64, device=dev)
+    per_rank = [mine]
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
-        dist.all_reduce(kern_max, op=dist.ReduceOp.MAX)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     elapsed = float(t.item())
+    my = [int(x) for x in counters.tolist()]
+    if world > 1:
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
     c = [int(x) for x in counters.tolist()]
-    steps = max(args.steps, 1)
+    per_rank = [[float(x) for x in r.tolist()] for r in per_rank]
+    slow = max(range(world), key=lambda r: per_rank[r][1])        # the rank with the longest integrate kernel
+    # counters of the slowest rank (its kernel is the one priced): exchange wave_iters / clock words
+    mine_k = torch.tensor([my[ltrace.STAT_WAVE_ITERS], my[ltrace.STAT_WAVES], my[ltrace.STAT_CLK_CYCLES],
+                           my[ltrace.STAT_CLK_TICKS], my[ltrace.STAT_STEPS], my[ltrace.STAT_RAYS]], dtype=torch.int64, device=dev)
+    all_k = [mine_k]
+    if world > 1:
+        all_k = [torch.zeros_like(mine_k) for _ in range(world)]
+        dist.all_gather(all_k, mine_k)
+    all_k = [[int(x) for x in k.tolist()] for k in all_k]
+
     rays_per_frame = c[ltrace.STAT_RAYS] // steps
     rk_steps = c[ltrace.STAT_STEPS] / steps
-    if args.metric == "kerr":
-        if args.integrator == "dp45":
-            flops_frame = rk_steps * F_DP45_ATTEMPT + rays_per_frame * (F_KERR_FIXED + 188)
-        else:
-            flops_frame = rk_steps * F_RK4_STEP + rays_per_frame * F_KERR_FIXED
-    else:
-        flops_frame = rk_steps * F_SCHW_STEP + rays_per_frame * F_SCHW_FIXED
     ms_per_step = elapsed / steps * 1e3
     value = rays_per_frame / (elapsed / steps) / 1e6
 
+    # untimed extras (rank 0, one GPU): longest-ray chain and the host-pointer end-to-end frame
+    chain = e2e = None
+    if rank == 0 and world == 1 and not args.no_extras and args.metric == "kerr":
+        d_steps = torch.empty((size, size), dtype=torch.int32, device=dev)
+        o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
+        o1.stream = stream.cuda_stream
+        ltrace.render_dev(cam, met, o1, d_steps=d_steps.data_ptr())
+        torch.cuda.synchronize(dev)
+        chain = longest_chain(ltrace, cam, met, args, d_steps.cpu().numpy(), np)
+        del d_steps
+        if not args.background:
+            e2e = end_to_end(ltrace, cam, met, args, np)
+
     if rank == 0:
-        # HBM bytes per launch of the integrate kernel: PMC counters cannot be read from inside this
-        # process, so the figure comes from the committed rocprofv3 pass for this exact workload
         spin = args.a if args.metric == "kerr" else 0.0
         workload = f"{args.metric}_a{spin}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                rec = json.load(f).get(workload)
-            if rec and world == 1 and args.precision == 32 and not args.background:
-                traffic = rec.get(args.schedule)
-        except OSError:
-            pass
-        integ_ms = float(kern_max[1].item()) / steps          # slowest rank's average integrate-kernel time
-        achieved = (flops_frame / world) / (integ_ms * 1e-3) / 1e12 if integ_ms > 0 else 0.0
+        if args.background:
+            workload += "_lensed_background"
+        kernel = (f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct")
+        key = f"{workload}|f{args.precision}|{args.schedule}|parts{world}"
+        bid = ltrace.build_id()
+        # --- executed work of the priced launch (the slowest rank's integrate kernel)
+        k_iters, k_waves, k_cyc, k_ticks, k_steps, k_rays = all_k[slow]
+        integ_ms = per_rank[slow][1]
+        iters_per_launch = k_iters / steps
+        vc = load_profile_json("valu_counts.json")
+        rec = (vc.get("workloads") or {}).get(key) or (vc.get("workloads") or {}).get(f"{workload}|f{args.precision}|{args.schedule}|parts1")
+        valu_src, valu_per_iter = None, None
+        if rec and rec.get("wave_iters"):
+            valu_per_iter = rec["valu_insts"] / rec["wave_iters"]
+            fresh = vc.get("build_id") == bid
+            valu_src = (f"{rec.get('source', 'profiles/valu_counts.json')}: SQ_INSTS_VALU {rec['valu_insts']} / wave_iters "
+                        f"{rec['wave_iters']} per launch" + ("" if fresh else f"; STALE: measured on build {vc.get('build_id')}, this is {bid}"))
         peak = PEAK_FP32_VALU_TFLOPS if args.precision == 32 else PEAK_FP64_VALU_TFLOPS
+        cyc = CYCLES_PER_VALU[args.precision]
+        clock_mhz = k_cyc / k_ticks * 100.0 if k_ticks else None
+        roof = {"bound": "valu_issue_fp32" if args.precision == 32 else "valu_issue_fp64", "kernel": kernel,
+                "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "avg_launch_ms": round(integ_ms, 4), "priced_rank": slow}
+        if valu_per_iter and integ_ms > 0:
+            valu = valu_per_iter * iters_per_launch               # wave-instructions this launch issued
+            slots_per_s = valu / (integ_ms * 1e-3)
+            peak_slots = N_SIMD * NOMINAL_CLOCK_HZ / cyc
+            lane_flops = 64 * 2                                   # one FMA per lane per issue slot
+            roof["achieved"] = round(slots_per_s * lane_flops / 1e12, 2)   # FMA-equivalent: every issue slot priced as one FMA
+            roof["frac"] = round(slots_per_s / peak_slots, 4)
+            roof["executed"] = {"valu_wave_insts_per_launch": int(valu), "wave_iters_per_launch": int(iters_per_launch),
+                                "valu_per_wave_iter": round(valu_per_iter, 2), "waves": int(k_waves / steps),
+                                "issue_cycles_per_inst": cyc, "source": valu_src,
+                                "clock_mhz_held": round(clock_mhz, 1) if clock_mhz else None,
+                                "frac_at_held_clock": round(slots_per_s / (N_SIMD * clock_mhz * 1e6 / cyc), 4) if clock_mhz else None}
+        else:
+            roof["executed"] = {"wave_iters_per_launch": int(iters_per_launch), "source": "no VALU count for this workload under profiles/ "
+                                "(tools/refresh_profiles.sh); frac left null rather than guessed"}
+        # --- the reference's as-written count, for the record
+        slow_steps, slow_rays = k_steps / steps, k_rays / steps
+        if args.metric == "kerr":
+            flops = (slow_steps * F_DP45_ATTEMPT + slow_rays * (F_KERR_FIXED + 188)) if args.integrator == "dp45" else \
+                    (slow_steps * F_RK4_STEP + slow_rays * F_KERR_FIXED)
+        else:
+            flops = slow_steps * F_SCHW_STEP + slow_rays * F_SCHW_FIXED
+        aw = flops / (integ_ms * 1e-3) / 1e12 if integ_ms > 0 else 0.0
+        roof["algorithmic_as_written"] = {"flops_per_launch": int(flops), "tflops": round(aw, 2), "of_peak": round(aw / peak, 4),
+                                          "note": "the reference's un-simplified op count (832 per RK4 step); the kernel executes "
+                                                  "about a third of it, so this can exceed 1 and is not a roofline fraction"}
+        # --- HBM traffic of the integrate kernel: only from a PMC pass of THIS build on THIS workload
+        tr = load_profile_json("hbm_traffic.json")
+        trec = (tr.get("workloads") or {}).get(key)
+        if trec and tr.get("build_id") == bid:
+            roof["traffic"] = trec["bytes_per_launch"]
+            roof["traffic_source"] = trec.get("source")
+        roof["algorithmic_bytes_per_launch"] = int(k_waves / steps * 64 * 12 * (4 if args.precision == 32 else 8))
+        roof["other_kernels_ms"] = {"prologue": round(per_rank[slow][0], 4), "epilogue": round(per_rank[slow][2], 4)}
         out = {
             "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
-            "config": {"workload": workload
-                                   + ("_lensed_background" if args.background else ""),
-                       "rays_per_frame": rays_per_frame, "schedule": args.schedule,
+            "config": {"workload": workload,
+                       "rays_per_frame": rays_per_frame, "schedule": args.schedule, "build_id": bid, "profile_key": key,
                        "row_partition": f"block-cyclic {rb} rows x {world}", "gather": "rccl" if world > 1 else "none",
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
                        "invalid": c[ltrace.STAT_INVALID] // steps},
-            "roofline": {"bound": "valu_fp32" if args.precision == 32 else "valu_fp64", "kernel": f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct",
-                         "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "algorithmic_flops_per_launch": int(flops_frame / world),
-                         "avg_launch_ms": round(integ_ms, 4),
-                         "other_kernels_ms": {"prologue": round(float(kern_max[0].item()) / steps, 4),
-                                              "epilogue": round(float(kern_max[2].item()) / steps, 4)}},
+            "roofline": roof,
+            "ranks": {"rccl_world": rccl_world,
+                      "integrate_ms": [round(r[1], 3) for r in per_rank],
+                      "render_ms": [round(r[3], 3) for r in per_rank],
+                      "gather_ms": [round(r[4], 3) for r in per_rank]},
         }
+        if chain:
+            out["chain_floor"] = chain
+        if e2e:
+            out["end_to_end_ms"] = e2e
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, fov)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

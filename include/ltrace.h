@@ -14,13 +14,14 @@
 #ifndef LTRACE_H
 #define LTRACE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define LT_VERSION 100 /* 0.1.0 */
+#define LT_VERSION 200 /* 0.2.0: lt_stats grew to 16 counters; per-stream workspaces; lt_render_multi */
 
 #define LT_OK 0
 #define LT_ERR_INVALID_ARG (-1)
@@ -89,7 +90,13 @@ typedef struct lt_opts {
 #define LT_STAT_ESCAPED 3
 #define LT_STAT_CAPTURED 4
 #define LT_STAT_INVALID 5
-#define LT_STAT_WORDS 8
+/* Produced by the integrate kernel itself (Kerr; zero for Schwarzschild): the work it issued and the
+ * clock the chip held while it ran.  bench.py prices its executed-instruction roofline in these. */
+#define LT_STAT_WAVE_ITERS 6 /* sum over wavefronts of integrator loop iterations the wavefront issued */
+#define LT_STAT_WAVES 7      /* wavefronts of the integrate kernel                                     */
+#define LT_STAT_CLK_CYCLES 8 /* shader-clock cycles (s_memtime) over the lifetime of every 64th wave   */
+#define LT_STAT_CLK_TICKS 9  /* 100 MHz real-time ticks (s_memrealtime) over the same lifetimes        */
+#define LT_STAT_WORDS 16
 
 typedef struct lt_stats {
     uint64_t counters[LT_STAT_WORDS];
@@ -98,10 +105,22 @@ typedef struct lt_stats {
 
 /* ---- library / device ------------------------------------------------------------- */
 int lt_version(void);
+/* Hash of the kernel sources and compiler flags this binary was built from (set by the build script);
+ * profiles under profiles/ carry it so that a figure measured on another build is never reused. */
+const char *lt_build_id(void);
 const char *lt_last_error(void);
 int lt_device_count(void);
 int lt_set_device(int device);
-/* Frees workspaces and events created lazily by the calls below. */
+/* Frees workspaces, staging buffers and events created lazily by the calls below.
+ *
+ * Concurrency contract.  Everything the library allocates on a caller's behalf -- the ray records of
+ * lt_render_dev, the device-side outputs and the pinned staging of lt_render and of the batch twins --
+ * is owned per (device, stream): calls on DIFFERENT streams of a device never share memory and may be
+ * in flight at the same time; calls on the SAME stream are ordered by the stream.  The host-pointer
+ * entry points (lt_render, lt_trace_batch_*, lt_integrate_dense ...) are synchronous and must not be
+ * entered from two host threads with the same stream at once.  The batch twins always use the default
+ * (NULL) stream, like the reference's synchronous calls.  Buffers grow to the largest frame seen and are
+ * then reused: nothing is allocated per call. */
 int lt_shutdown(void);
 void lt_default_opts(lt_opts *o);
 
@@ -158,12 +177,31 @@ int lt_render_dev(const lt_camera *cam, const lt_metric *metric, const lt_opts *
                   int8_t *d_status, uint32_t *d_steps, float *d_rgb, uint8_t *d_rgba,
                   uint64_t *d_stats);
 
-/* Same with HOST pointers (stages the background H2D, results D2H, synchronises);
- * stats may be NULL. */
+/* Same with HOST pointers (stages the background H2D, results D2H, synchronises); stats may be NULL.
+ * Device-side buffers persist per (device, stream).  A destination inside a block from lt_host_alloc
+ * (or any other pinned / registered host memory) is written by DMA directly; a pageable destination is
+ * filled through the library's pinned staging area by host threads while later pieces still cross PCIe
+ * (LT_D2H_THREADS, default 6; LT_D2H_PIECE_KB, default 4096). */
 int lt_render(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts,
               const float *bg, int32_t bg_channels, float *out_fa, uint16_t *out_w,
               int8_t *out_status, uint32_t *out_steps, float *out_rgb, uint8_t *out_rgba,
               lt_stats *stats);
+
+/* Pinned host memory for the outputs of the host-pointer entry points (NULL on failure, see
+ * lt_last_error); ltrace.py hands such blocks out as numpy arrays. */
+void *lt_host_alloc(size_t bytes);
+int lt_host_free(void *p);
+
+/* One frame on several GPUs of this node from ONE process (SURVEY 8b `lt_render_multi`): partition p of
+ * n_gpus (block-cyclic rows, opts->row_block; opts->n_parts / part / stream are ignored) is rendered on
+ * device devices[p] (NULL: device p), all partitions concurrently, and every device copies its rows
+ * straight into the caller's full-frame HOST arrays -- no device-to-device gather.  `devices` may name
+ * one device several times (partitions then queue on it).  Outputs as lt_render, sized for the FULL
+ * (H, W) frame; stats sums the counters and takes the slowest device's kernel times.
+ * The RCCL gather of the north-star contract is the multi-process path (sharding.FrameGather / bench.py). */
+int lt_render_multi(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, int32_t n_gpus,
+                    const int32_t *devices, const float *bg, int32_t bg_channels, float *out_fa, uint16_t *out_w,
+                    int8_t *out_status, uint32_t *out_steps, float *out_rgb, uint8_t *out_rgba, lt_stats *stats);
 
 /* ---- the first and the last stage on their own (HOST pointers) ------------------------------ *
  * The reference's pipeline is three calls; lt_render fuses them, these keep each call a GPU twin. */
@@ -230,26 +268,6 @@ int lt_rhs8_probe(const lt_metric *metric, const double *states, int64_t n, doub
  * lt_render_dev calls made with opts->timing != 0 since the last collect; *calls = how many.
  * Synchronises on the recorded events. */
 int lt_timing_collect(double *prologue_ms, double *integrate_ms, double *epilogue_ms, int32_t *calls);
-
-/* FP32 VALU issue-rate microbenchmark used to calibrate the roofline: runs `iters` dependent-chain
- * FMA blocks per lane; mode 0 = v_fma_f32, 1 = v_pk_fma_f32.  Returns achieved TFLOP/s in *tflops. */
-int lt_valu_peak_probe(int mode, int iters, double *tflops);
-
-/* VALU issue-cost microbenchmark (diagnostic; DESIGN.md "issue-rate roofline"): instruction class
- * `index` in [0, lt_valu_issue_probe_count()), `waves_per_simd` resident waves per SIMD (1..8).
- * constant_data != 0 runs it on all-equal operands (no datapath toggling: highest clock).
- * Returns ns per wave-instruction per SIMD and the shader clock the chip held during the loop
- * (s_memtime / s_memrealtime); name_out receives the instruction mnemonic. */
-int lt_valu_issue_probe(int index, int waves_per_simd, int iters, int constant_data, char *name_out,
-                        int name_len, double *ns_per_instr, double *clock_mhz);
-int lt_valu_issue_probe_count(void);
-/* The Kerr RK4 step alone (no events, no divergence), `iters` times per lane, `waves_per_simd`
- * resident waves per SIMD: shader cycles one SIMD spends per wave-step, and the clock held. */
-/* Pieces of the right-hand side (0 sincos, 1 the rest, 2 the rest without the reciprocal): SIMD
- * cycles per evaluation per wave. */
-int lt_piece_probe(int piece, int waves_per_simd, int iters, double *cycles_per_eval, double *clock_mhz);
-int lt_rk4_step_probe(int precision, int waves_per_simd, int iters, double *cycles_per_wave_step,
-                      double *clock_mhz);
 
 #ifdef __cplusplus
 }

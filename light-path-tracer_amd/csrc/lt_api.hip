@@ -5,7 +5,9 @@
 // HIP events.  No CPU compute path exists: without a GPU the entry points fail.
 #include "../../include/ltrace.h"
 #include "lt_kernels.hpp"
+#ifdef LT_PROBES
 #include "lt_probe.hpp"
+#endif
 #include "lt_dense.hpp"
 
 #include <cmath>
@@ -14,7 +16,12 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
+
+#ifndef LT_BUILD_ID
+#define LT_BUILD_ID "unversioned"
+#endif
 
 using namespace lt;
 
@@ -40,6 +47,7 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" int lt_version(void) { return LT_VERSION; }
+extern "C" const char *lt_build_id(void) { return LT_BUILD_ID; }
 extern "C" const char *lt_last_error(void) { return g_err; }
 
 extern "C" int lt_device_count(void)
@@ -64,19 +72,39 @@ static int require_device()
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-device context: grow-only workspace for the ray records, timing events
+// per-device context.  Everything a call needs beyond the caller's own buffers is owned per
+// (device, stream): the grow-only workspace of ray records, and for the host-pointer entry points
+// the device-side outputs and a pinned staging area.  Two calls on different streams of one device
+// therefore never share memory and may run concurrently; calls on the same stream are ordered by
+// the stream.  Nothing is allocated per call once the buffers have grown to the frame size.
 // ---------------------------------------------------------------------------------------------
 struct EventQuad { hipEvent_t e[4]; };
 
+struct Grow { // grow-only allocation (device memory, or pinned host memory when `host` is set)
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool host = false;
+};
+
+struct StreamSlot {
+    hipStream_t stream = nullptr;
+    Grow ws;     // ray records of lt_render_dev / the batch twins
+    Grow dev;    // lt_render / batch twins: device-side inputs and outputs
+    Grow pinned; // lt_render: pinned host staging for destinations that are not pinned themselves
+    EventQuad own{}; // lt_render's private timing events (created on first use)
+    bool own_ok = false;
+};
+
 struct Ctx {
-    void *ws = nullptr;
-    size_t ws_bytes = 0;
-    std::vector<EventQuad> pending; // recorded, not yet collected
+    std::vector<StreamSlot *> slots;
+    std::vector<EventQuad> pending; // recorded by lt_render_dev(timing=1), not yet collected
     std::vector<EventQuad> pool;
 };
 
 static std::mutex g_mu;
 static Ctx g_ctx[64];
+struct MultiStream { int dev, idx; hipStream_t s; }; // lt_render_multi: one stream per (device, partition)
+static std::vector<MultiStream> g_multi_streams;
 
 static int cur_ctx(Ctx **out)
 {
@@ -87,35 +115,69 @@ static int cur_ctx(Ctx **out)
     return LT_OK;
 }
 
-// Workspace layout: 256 B of control words (queue head) | ic[n_q] | fin0[n_q] | fin1[n_q], each a
-// 4-vector of T.
-struct Workspace { uint32_t *head; void *ic, *fin0, *fin1; };
-
-static int get_workspace(size_t n_q, size_t elem, Workspace *w)
+static int get_slot(hipStream_t s, StreamSlot **out)
 {
     Ctx *c;
     int rc = cur_ctx(&c);
     if (rc) return rc;
-    size_t vec = 4 * elem;
-    size_t need = 256 + 3 * n_q * vec;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (need > c->ws_bytes) {
-        if (c->ws) {
-            HIP_TRY(hipDeviceSynchronize());
-            HIP_TRY(hipFree(c->ws));
-            c->ws = nullptr;
-            c->ws_bytes = 0;
-        }
-        HIP_TRY(hipMalloc(&c->ws, need));
-        c->ws_bytes = need;
+    for (StreamSlot *sl : c->slots)
+        if (sl->stream == s) { *out = sl; return LT_OK; }
+    StreamSlot *sl = new StreamSlot;
+    sl->stream = s;
+    c->slots.push_back(sl);
+    *out = sl;
+    return LT_OK;
+}
+
+// Only `stream` ever touches the buffer, so draining that stream is enough before it is replaced.
+static int grow(Grow &g, size_t need, hipStream_t stream)
+{
+    if (need <= g.bytes) return LT_OK;
+    if (g.p) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (g.host) HIP_TRY(hipHostFree(g.p)); else HIP_TRY(hipFree(g.p));
+        g.p = nullptr;
+        g.bytes = 0;
     }
-    char *base = (char *)c->ws;
-    w->head = (uint32_t *)base;
+    need = (need + 4095) & ~(size_t)4095;
+    if (g.host) HIP_TRY(hipHostMalloc(&g.p, need, hipHostMallocDefault)); else HIP_TRY(hipMalloc(&g.p, need));
+    g.bytes = need;
+    return LT_OK;
+}
+
+static void release(Grow &g)
+{
+    if (!g.p) return;
+    if (g.host) (void)hipHostFree(g.p); else (void)hipFree(g.p);
+    g.p = nullptr;
+    g.bytes = 0;
+}
+
+// Workspace layout: 256 B of control words (queue head) | ic[n_q] | fin0[n_q] | fin1[n_q], each a
+// 4-vector of T.
+struct Workspace { unsigned long long *head; void *ic, *fin0, *fin1; };
+
+static int get_workspace(hipStream_t stream, size_t n_q, size_t elem, Workspace *w)
+{
+    StreamSlot *sl;
+    int rc = get_slot(stream, &sl);
+    if (rc) return rc;
+    size_t vec = 4 * elem;
+    if ((rc = grow(sl->ws, 256 + 3 * n_q * vec, stream))) return rc;
+    char *base = (char *)sl->ws.p;
+    w->head = (unsigned long long *)base;
     w->ic = base + 256;
     w->fin0 = base + 256 + n_q * vec;
     w->fin1 = base + 256 + 2 * n_q * vec;
     return LT_OK;
 }
+
+// Carves 256-byte aligned pieces out of one grow-only buffer.
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; }
+};
 
 static int env_int(const char *name, int dflt)
 {
@@ -145,17 +207,25 @@ extern "C" int lt_shutdown(void)
     if (n > 0) (void)hipGetDevice(&keep);
     for (int d = 0; d < n && d < 64; ++d) {
         Ctx &c = g_ctx[d];
-        if (!c.ws && c.pool.empty() && c.pending.empty()) continue;
+        if (c.slots.empty() && c.pool.empty() && c.pending.empty()) continue;
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
-        if (c.ws) (void)hipFree(c.ws);
-        c.ws = nullptr;
-        c.ws_bytes = 0;
+        for (StreamSlot *sl : c.slots) {
+            release(sl->ws); release(sl->dev); release(sl->pinned);
+            if (sl->own_ok) for (auto &e : sl->own.e) (void)hipEventDestroy(e);
+            delete sl;
+        }
+        c.slots.clear();
         for (auto &q : c.pending) for (auto &e : q.e) (void)hipEventDestroy(e);
         for (auto &q : c.pool) for (auto &e : q.e) (void)hipEventDestroy(e);
         c.pending.clear();
         c.pool.clear();
     }
+    for (auto &m : g_multi_streams) {
+        (void)hipSetDevice(m.dev);
+        (void)hipStreamDestroy(m.s);
+    }
+    g_multi_streams.clear();
     if (n > 0) (void)hipSetDevice(keep);
     return LT_OK;
 }
@@ -299,19 +369,39 @@ template <typename T> static SchwConsts<T> make_schw(const MetricConsts &mc, dou
 // ---------------------------------------------------------------------------------------------
 // stage launchers
 // ---------------------------------------------------------------------------------------------
+// Brackets the three kernels of one frame with HIP events.  Two modes: a quad from the device's pool that
+// ends up on the `pending` list for lt_timing_collect (lt_render_dev with opts->timing), or a caller-owned
+// quad (lt_render's private one, read directly).  A quad taken from the pool goes back to it on every
+// path that does not finish().
 struct Timer {
-    bool on = false;
+    bool on = false, pooled = false, done = false;
     EventQuad q{};
     Ctx *ctx = nullptr;
-    int begin(bool enable)
+    ~Timer()
     {
-        on = enable;
-        if (!on) return LT_OK;
+        if (on && pooled && !done) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            ctx->pool.push_back(q);
+        }
+    }
+    int begin(bool enable, const EventQuad *own)
+    {
+        if (own) { on = true; q = *own; return LT_OK; }
+        if (!enable) return LT_OK;
         int rc = cur_ctx(&ctx);
         if (rc) return rc;
         std::lock_guard<std::mutex> lk(g_mu);
         if (!ctx->pool.empty()) { q = ctx->pool.back(); ctx->pool.pop_back(); }
-        else for (auto &e : q.e) HIP_TRY(hipEventCreate(&e));
+        else {
+            for (int i = 0; i < 4; ++i) {
+                hipError_t e = hipEventCreate(&q.e[i]);
+                if (e != hipSuccess) {
+                    for (int j = 0; j < i; ++j) (void)hipEventDestroy(q.e[j]);
+                    return fail(LT_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+                }
+            }
+        }
+        on = pooled = true;
         return LT_OK;
     }
     int mark(int i, hipStream_t s)
@@ -321,9 +411,10 @@ struct Timer {
     }
     void finish()
     {
-        if (!on) return;
+        if (!on || !pooled) return;
         std::lock_guard<std::mutex> lk(g_mu);
         ctx->pending.push_back(q);
+        done = true;
     }
 };
 
@@ -379,7 +470,7 @@ struct StampDump {
 
 template <typename T>
 static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lambda_max, const Workspace &w,
-                            int64_t n_q, hipStream_t s)
+                            int64_t n_q, hipStream_t s, uint64_t *kstats)
 {
     using V = typename Vec4<T>::type;
     int rc;
@@ -398,10 +489,9 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
             static const int long_iters = env_int("LT_D_LONG", 1024);
             if ((rc = sd.begin((size_t)(n_q / 64)))) return rc;
-            if constexpr (sizeof(T) == 8) { if (dp45) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev); }
-            if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev);
+            if constexpr (sizeof(T) == 8) { if (dp45) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats); }
+            if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats);
         } else {
-            if (n_q >= (int64_t)1 << 32) return fail(LT_ERR_UNSUPPORTED, "queue schedule: more than 2^32 rays");
             int cus;
             if ((rc = cu_count(&cus))) return rc;
             // persistent grid: blocks-per-CU x CUs, never more blocks than there are 256-ray pieces
@@ -411,17 +501,18 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             static const int long_steps = env_int("LT_Q_LONG", 600);
             unsigned qgrid = (unsigned)(cus * bpc);
             if (qgrid > grid) qgrid = grid;
-            HIP_TRY(hipMemsetAsync(w.head, 0, sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(w.head, 0, sizeof(unsigned long long), s));
             if ((rc = sd.begin((size_t)qgrid * 4))) return rc;
             if constexpr (sizeof(T) == 8) {
                 if (dp45) // "long" is measured in step attempts: DP45 rays take ~50, not ~150
-                    k_kerr_queue<T, Dp45<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint32_t)n_q,
+                    k_kerr_queue<T, Dp45<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint64_t)n_q,
                                                                  w.head, (uint32_t)chunk, (uint32_t)refill_min,
-                                                                 (uint32_t)(long_steps / 3), sd.dev);
+                                                                 (uint32_t)(long_steps / 3), sd.dev, kstats);
             }
             if (!dp45)
-                k_kerr_queue<T, Rk4<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint32_t)n_q, w.head,
-                                                            (uint32_t)chunk, (uint32_t)refill_min, (uint32_t)long_steps, sd.dev);
+                k_kerr_queue<T, Rk4<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint64_t)n_q, w.head,
+                                                            (uint32_t)chunk, (uint32_t)refill_min, (uint32_t)long_steps, sd.dev,
+                                                            kstats);
         }
         HIP_TRY(hipGetLastError());
         if ((rc = sd.end())) return rc;
@@ -448,9 +539,9 @@ static int check_opts(const lt_metric *metric, lt_opts *o)
     return LT_OK;
 }
 
-extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, const float *d_bg,
-                             int32_t bg_channels, float *d_fa, uint16_t *d_w, int8_t *d_status, uint32_t *d_steps,
-                             float *d_rgb, uint8_t *d_rgba, uint64_t *d_stats)
+static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, const float *d_bg,
+                           int32_t bg_channels, float *d_fa, uint16_t *d_w, int8_t *d_status, uint32_t *d_steps,
+                           float *d_rgb, uint8_t *d_rgba, uint64_t *d_stats, const EventQuad *own_events)
 {
     int rc = require_device();
     if (rc) return rc;
@@ -538,10 +629,10 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     hipStream_t s = (hipStream_t)o.stream;
     size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
     Workspace w;
-    if ((rc = get_workspace((size_t)n_q, elem, &w))) return rc;
+    if ((rc = get_workspace(s, (size_t)n_q, elem, &w))) return rc;
     void *ic = w.ic, *fin0 = w.fin0, *fin1 = w.fin1;
     Timer tm;
-    if ((rc = tm.begin(o.timing != 0))) return rc;
+    if ((rc = tm.begin(o.timing != 0, own_events))) return rc;
     unsigned gq = (unsigned)((n_q + 255) / 256);
     int64_t n_pix = (int64_t)c.rows_local * c.W;
     unsigned gp = (unsigned)((n_pix + 255) / 256);
@@ -553,8 +644,8 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     else k_prologue_camera<double><<<gq, 256, 0, s>>>(c, mc, (double4 *)ic, n_q);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.mark(1, s))) return rc;
-    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, w, n_q, s)
-                           : launch_integrate<double>(mc, o, lambda_max, w, n_q, s);
+    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, w, n_q, s, d_stats)
+                           : launch_integrate<double>(mc, o, lambda_max, w, n_q, s, d_stats);
     if (rc) return rc;
     if ((rc = tm.mark(2, s))) return rc;
     if (o.precision == 32) k_epilogue_frame<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
@@ -565,12 +656,109 @@ extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, cons
     return LT_OK;
 }
 
+extern "C" int lt_render_dev(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, const float *d_bg,
+                             int32_t bg_channels, float *d_fa, uint16_t *d_w, int8_t *d_status, uint32_t *d_steps,
+                             float *d_rgb, uint8_t *d_rgba, uint64_t *d_stats)
+{
+    return render_dev_impl(cam, metric, opts, d_bg, bg_channels, d_fa, d_w, d_status, d_steps, d_rgb, d_rgba, d_stats,
+                           nullptr);
+}
+
 // RAII device buffer for the host-pointer entry points
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n) { HIP_TRY(hipMalloc(&p, n ? n : 1)); return LT_OK; }
 };
+
+// ---- pinned host memory for callers of the host-pointer entry points ---------------------------
+// A destination inside such a block is written by DMA straight from the device (PCIe rate); any other
+// destination is pageable memory and goes through the library's pinned staging + host copies.
+extern "C" void *lt_host_alloc(size_t bytes)
+{
+    if (lt_device_count() <= 0) { (void)fail(LT_ERR_NO_DEVICE, "lt_host_alloc: no HIP device visible"); return nullptr; }
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { (void)fail(LT_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+extern "C" int lt_host_free(void *p)
+{
+    if (!p) return LT_OK;
+    HIP_TRY(hipHostFree(p));
+    return LT_OK;
+}
+
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Device -> host for a list of outputs.  Pinned destinations: one async DMA each.  Pageable destinations: the
+// bytes are cut into pieces that are DMA'd into the slot's pinned staging area back to back, each piece followed
+// by an event; host threads copy piece i to its destination as soon as its event has fired, i.e. while the
+// later pieces are still crossing PCIe.
+struct OutCopy { void *dst; const void *src; size_t bytes; };
+
+static int copy_out(StreamSlot *sl, hipStream_t s, const std::vector<OutCopy> &outs)
+{
+    struct Piece { char *dst; const char *stage; size_t bytes; hipEvent_t ev; };
+    static const size_t piece_bytes = (size_t)env_int("LT_D2H_PIECE_KB", 4096) * 1024;
+    size_t staged = 0;
+    for (const OutCopy &o : outs)
+        if (o.bytes && !is_pinned_host(o.dst)) staged += (o.bytes + 255) & ~(size_t)255;
+    int rc;
+    if ((rc = grow(sl->pinned, staged, s))) return rc;
+    std::vector<Piece> pieces;
+    size_t off = 0;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    for (const OutCopy &o : outs) {
+        if (!o.bytes) continue;
+        if (is_pinned_host(o.dst)) {
+            HIP_TRY(hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToHost, s));
+            continue;
+        }
+        char *stage = (char *)sl->pinned.p + off;
+        off += (o.bytes + 255) & ~(size_t)255;
+        for (size_t b = 0; b < o.bytes; b += piece_bytes) {
+            size_t len = o.bytes - b < piece_bytes ? o.bytes - b : piece_bytes;
+            Piece pc{(char *)o.dst + b, stage + b, len, nullptr};
+            HIP_TRY(hipMemcpyAsync((void *)pc.stage, (const char *)o.src + b, len, hipMemcpyDeviceToHost, s));
+            hipError_t e = hipEventCreateWithFlags(&pc.ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(pc.ev, s);
+            if (e != hipSuccess) {
+                for (Piece &q : pieces) (void)hipEventDestroy(q.ev);
+                return fail(LT_ERR_HIP, "event for a device-to-host piece: %s", hipGetErrorString(e));
+            }
+            pieces.push_back(pc);
+        }
+    }
+    if (!pieces.empty()) {
+        static const int max_threads = env_int("LT_D2H_THREADS", 6);
+        int nt = (int)pieces.size() < max_threads ? (int)pieces.size() : max_threads;
+        if (nt < 1) nt = 1;
+        std::vector<int> errs((size_t)nt, 0);
+        auto work = [&](int t) {
+            (void)hipSetDevice(dev);
+            for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)nt) {
+                if (hipEventSynchronize(pieces[i].ev) != hipSuccess) { errs[(size_t)t] = 1; continue; }
+                memcpy(pieces[i].dst, pieces[i].stage, pieces[i].bytes);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &t : th) t.join();
+        for (Piece &q : pieces) (void)hipEventDestroy(q.ev);
+        for (int e : errs) if (e) return fail(LT_ERR_HIP, "waiting for a device-to-host piece failed");
+    }
+    return LT_OK;
+}
 
 extern "C" int lt_render(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, const float *bg,
                          int32_t bg_channels, float *out_fa, uint16_t *out_w, int8_t *out_status, uint32_t *out_steps,
@@ -583,41 +771,172 @@ extern "C" int lt_render(const lt_camera *cam, const lt_metric *metric, const lt
     if ((rc = check_opts(metric, &o))) return rc;
     int64_t rows = lt_local_rows(cam->height, o.row_block, o.n_parts, o.part);
     if (rows < 0 || cam->width <= 0) return fail(LT_ERR_INVALID_ARG, "bad frame / partition");
+    if (bg && bg_channels != 1 && bg_channels != 3) return fail(LT_ERR_INVALID_ARG, "bg_channels must be 1 or 3");
     size_t n = (size_t)rows * cam->width;
     size_t n_full = (size_t)cam->height * cam->width;
     int nch = bg ? bg_channels : 3;
     hipStream_t s = (hipStream_t)o.stream;
-    DevBuf dbg, dfa, dw, dst, dsteps, drgb, drgba, dstats;
-    if (bg) {
-        if ((rc = dbg.alloc(n_full * bg_channels * sizeof(float)))) return rc;
-        HIP_TRY(hipMemcpyAsync(dbg.p, bg, n_full * bg_channels * sizeof(float), hipMemcpyHostToDevice, s));
+    StreamSlot *sl;
+    if ((rc = get_slot(s, &sl))) return rc;
+    // device-side inputs / outputs: pieces of ONE grow-only buffer of this (device, stream) -- nothing is
+    // allocated per call once it has reached the frame size
+    Carver cv;
+    size_t o_stats = cv.take(LT_STAT_WORDS * 8);
+    size_t o_bg = bg ? cv.take(n_full * bg_channels * sizeof(float)) : 0;
+    size_t o_fa = out_fa ? cv.take(n * 4) : 0, o_w = out_w ? cv.take(n * 2) : 0, o_st = out_status ? cv.take(n) : 0;
+    size_t o_steps = out_steps ? cv.take(n * 4) : 0, o_rgb = out_rgb ? cv.take(n * nch * 4) : 0;
+    size_t o_rgba = out_rgba ? cv.take(n * 4) : 0;
+    if ((rc = grow(sl->dev, cv.off, s))) return rc;
+    char *base = (char *)sl->dev.p;
+    auto at = [&](bool want, size_t off) -> void * { return want ? (void *)(base + off) : nullptr; };
+    if (bg) HIP_TRY(hipMemcpyAsync(base + o_bg, bg, n_full * bg_channels * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(base + o_stats, 0, LT_STAT_WORDS * 8, s));
+    if (!sl->own_ok) {
+        for (auto &e : sl->own.e) HIP_TRY(hipEventCreate(&e));
+        sl->own_ok = true;
     }
-    if (out_fa && (rc = dfa.alloc(n * 4))) return rc;
-    if (out_w && (rc = dw.alloc(n * 2))) return rc;
-    if (out_status && (rc = dst.alloc(n))) return rc;
-    if (out_steps && (rc = dsteps.alloc(n * 4))) return rc;
-    if (out_rgb && (rc = drgb.alloc(n * nch * 4))) return rc;
-    if (out_rgba && (rc = drgba.alloc(n * 4))) return rc;
-    if ((rc = dstats.alloc(LT_STAT_WORDS * 8))) return rc;
-    HIP_TRY(hipMemsetAsync(dstats.p, 0, LT_STAT_WORDS * 8, s));
-    o.timing = 1;
-    double t0, t1, t2; int32_t calls;
-    (void)lt_timing_collect(&t0, &t1, &t2, &calls); // drop stale events
-    rc = lt_render_dev(cam, metric, &o, (const float *)dbg.p, bg_channels, (float *)dfa.p, (uint16_t *)dw.p,
-                       (int8_t *)dst.p, (uint32_t *)dsteps.p, (float *)drgb.p, (uint8_t *)drgba.p, (uint64_t *)dstats.p);
+    o.timing = 0; // private events: concurrent lt_render_dev(timing = 1) callers keep theirs
+    rc = render_dev_impl(cam, metric, &o, (const float *)at(bg != nullptr, o_bg), bg_channels, (float *)at(out_fa, o_fa),
+                         (uint16_t *)at(out_w, o_w), (int8_t *)at(out_status, o_st), (uint32_t *)at(out_steps, o_steps),
+                         (float *)at(out_rgb, o_rgb), (uint8_t *)at(out_rgba, o_rgba), (uint64_t *)(base + o_stats),
+                         &sl->own);
     if (rc) return rc;
-    if (out_fa) HIP_TRY(hipMemcpyAsync(out_fa, dfa.p, n * 4, hipMemcpyDeviceToHost, s));
-    if (out_w) HIP_TRY(hipMemcpyAsync(out_w, dw.p, n * 2, hipMemcpyDeviceToHost, s));
-    if (out_status) HIP_TRY(hipMemcpyAsync(out_status, dst.p, n, hipMemcpyDeviceToHost, s));
-    if (out_steps) HIP_TRY(hipMemcpyAsync(out_steps, dsteps.p, n * 4, hipMemcpyDeviceToHost, s));
-    if (out_rgb) HIP_TRY(hipMemcpyAsync(out_rgb, drgb.p, n * nch * 4, hipMemcpyDeviceToHost, s));
-    if (out_rgba) HIP_TRY(hipMemcpyAsync(out_rgba, drgba.p, n * 4, hipMemcpyDeviceToHost, s));
     lt_stats st;
     memset(&st, 0, sizeof(st));
-    HIP_TRY(hipMemcpyAsync(st.counters, dstats.p, LT_STAT_WORDS * 8, hipMemcpyDeviceToHost, s));
+    std::vector<OutCopy> outs;
+    // small and first to be consumed go first; the framebuffer(s) follow
+    if (out_rgba) outs.push_back({out_rgba, base + o_rgba, n * 4});
+    if (out_fa) outs.push_back({out_fa, base + o_fa, n * 4});
+    if (out_w) outs.push_back({out_w, base + o_w, n * 2});
+    if (out_status) outs.push_back({out_status, base + o_st, n});
+    if (out_steps) outs.push_back({out_steps, base + o_steps, n * 4});
+    if (out_rgb) outs.push_back({out_rgb, base + o_rgb, n * nch * 4});
+    if ((rc = copy_out(sl, s, outs))) return rc;
+    HIP_TRY(hipMemcpyAsync(st.counters, base + o_stats, LT_STAT_WORDS * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if ((rc = lt_timing_collect(&st.prologue_ms, &st.integrate_ms, &st.epilogue_ms, &calls))) return rc;
+    if (rows > 0) {
+        float ms[3] = {0, 0, 0};
+        for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], sl->own.e[i], sl->own.e[i + 1]));
+        st.prologue_ms = ms[0]; st.integrate_ms = ms[1]; st.epilogue_ms = ms[2];
+    }
     if (stats) *stats = st;
+    return LT_OK;
+}
+
+// ---- one frame on several devices from one process ----------------------------------------------
+static int multi_stream(int dev, int idx, hipStream_t *out)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &m : g_multi_streams)
+        if (m.dev == dev && m.idx == idx) { *out = m.s; return LT_OK; }
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    g_multi_streams.push_back({dev, idx, s});
+    *out = s;
+    return LT_OK;
+}
+
+extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts, int32_t n_gpus,
+                               const int32_t *devices, const float *bg, int32_t bg_channels, float *out_fa,
+                               uint16_t *out_w, int8_t *out_status, uint32_t *out_steps, float *out_rgb,
+                               uint8_t *out_rgba, lt_stats *stats)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (!cam || !metric || !opts) return fail(LT_ERR_INVALID_ARG, "null camera / metric / opts");
+    if (n_gpus < 1 || n_gpus > 64) return fail(LT_ERR_INVALID_ARG, "n_gpus = %d", n_gpus);
+    if (cam->width <= 0 || cam->height <= 0) return fail(LT_ERR_INVALID_ARG, "empty frame %dx%d", cam->width, cam->height);
+    if (bg && bg_channels != 1 && bg_channels != 3) return fail(LT_ERR_INVALID_ARG, "bg_channels must be 1 or 3");
+    lt_opts o = *opts;
+    if ((rc = check_opts(metric, &o))) return rc;
+    const int n_dev = lt_device_count();
+    std::vector<int> dev((size_t)n_gpus);
+    for (int p = 0; p < n_gpus; ++p) {
+        dev[(size_t)p] = devices ? devices[p] : p;
+        if (dev[(size_t)p] < 0 || dev[(size_t)p] >= n_dev)
+            return fail(LT_ERR_INVALID_ARG, "partition %d wants device %d but %d device(s) are visible", p, dev[(size_t)p], n_dev);
+    }
+    int keep = 0;
+    HIP_TRY(hipGetDevice(&keep));
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{keep};
+
+    const int W = cam->width, H = cam->height, nch = bg ? bg_channels : 3;
+    const size_t n_full = (size_t)W * H;
+    struct Part { hipStream_t s; StreamSlot *sl; char *base; int64_t rows; size_t o_stats, o_fa, o_w, o_st, o_steps, o_rgb, o_rgba; };
+    std::vector<Part> parts((size_t)n_gpus);
+    // 1. launch every partition (asynchronous): all devices compute at the same time
+    for (int p = 0; p < n_gpus; ++p) {
+        Part &P = parts[(size_t)p];
+        HIP_TRY(hipSetDevice(dev[(size_t)p]));
+        if ((rc = multi_stream(dev[(size_t)p], p, &P.s))) return rc;
+        if ((rc = get_slot(P.s, &P.sl))) return rc;
+        P.rows = lt_local_rows(H, o.row_block, n_gpus, p);
+        size_t n = (size_t)P.rows * W;
+        Carver cv;
+        P.o_stats = cv.take(LT_STAT_WORDS * 8);
+        size_t o_bg = bg ? cv.take(n_full * bg_channels * sizeof(float)) : 0;
+        P.o_fa = out_fa ? cv.take(n * 4) : 0; P.o_w = out_w ? cv.take(n * 2) : 0; P.o_st = out_status ? cv.take(n) : 0;
+        P.o_steps = out_steps ? cv.take(n * 4) : 0; P.o_rgb = out_rgb ? cv.take(n * nch * 4) : 0;
+        P.o_rgba = out_rgba ? cv.take(n * 4) : 0;
+        if ((rc = grow(P.sl->dev, cv.off, P.s))) return rc;
+        P.base = (char *)P.sl->dev.p;
+        char *base = P.base;
+        auto at = [&](bool want, size_t off) -> void * { return want ? (void *)(base + off) : nullptr; };
+        if (bg) HIP_TRY(hipMemcpyAsync(base + o_bg, bg, n_full * bg_channels * sizeof(float), hipMemcpyHostToDevice, P.s));
+        HIP_TRY(hipMemsetAsync(base + P.o_stats, 0, LT_STAT_WORDS * 8, P.s));
+        if (!P.sl->own_ok) {
+            for (auto &e : P.sl->own.e) HIP_TRY(hipEventCreate(&e));
+            P.sl->own_ok = true;
+        }
+        lt_opts op = o;
+        op.n_parts = n_gpus; op.part = p; op.stream = (void *)P.s; op.timing = 0;
+        rc = render_dev_impl(cam, metric, &op, (const float *)at(bg != nullptr, o_bg), bg_channels, (float *)at(out_fa, P.o_fa),
+                             (uint16_t *)at(out_w, P.o_w), (int8_t *)at(out_status, P.o_st), (uint32_t *)at(out_steps, P.o_steps),
+                             (float *)at(out_rgb, P.o_rgb), (uint8_t *)at(out_rgba, P.o_rgba), (uint64_t *)(base + P.o_stats),
+                             &P.sl->own);
+        if (rc) return rc;
+    }
+    // 2. every device copies its row blocks to their place in the caller's full-frame arrays
+    lt_stats total;
+    memset(&total, 0, sizeof(total));
+    std::vector<lt_stats> each((size_t)n_gpus);
+    for (int p = 0; p < n_gpus; ++p) {
+        Part &P = parts[(size_t)p];
+        HIP_TRY(hipSetDevice(dev[(size_t)p]));
+        std::vector<OutCopy> outs;
+        auto rows_of = [&](void *dst, size_t off, size_t px_bytes) {
+            if (!dst) return;
+            size_t row_bytes = (size_t)W * px_bytes;
+            for (int64_t l0 = 0; l0 < P.rows; l0 += o.row_block) {
+                int64_t g0 = lt_global_row(l0, o.row_block, n_gpus, p);
+                int64_t nr = P.rows - l0 < o.row_block ? P.rows - l0 : o.row_block;
+                outs.push_back({(char *)dst + (size_t)g0 * row_bytes, P.base + off + (size_t)l0 * row_bytes, (size_t)nr * row_bytes});
+            }
+        };
+        rows_of(out_rgba, P.o_rgba, 4);
+        rows_of(out_fa, P.o_fa, 4);
+        rows_of(out_w, P.o_w, 2);
+        rows_of(out_status, P.o_st, 1);
+        rows_of(out_steps, P.o_steps, 4);
+        rows_of(out_rgb, P.o_rgb, (size_t)nch * 4);
+        if ((rc = copy_out(P.sl, P.s, outs))) return rc;
+        memset(&each[(size_t)p], 0, sizeof(lt_stats));
+        HIP_TRY(hipMemcpyAsync(each[(size_t)p].counters, P.base + P.o_stats, LT_STAT_WORDS * 8, hipMemcpyDeviceToHost, P.s));
+    }
+    for (int p = 0; p < n_gpus; ++p) {
+        Part &P = parts[(size_t)p];
+        HIP_TRY(hipSetDevice(dev[(size_t)p]));
+        HIP_TRY(hipStreamSynchronize(P.s));
+        for (int i = 0; i < LT_STAT_WORDS; ++i) total.counters[i] += each[(size_t)p].counters[i];
+        if (P.rows > 0) {
+            float ms[3] = {0, 0, 0};
+            for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], P.sl->own.e[i], P.sl->own.e[i + 1]));
+            if (ms[0] > total.prologue_ms) total.prologue_ms = ms[0];
+            if (ms[1] > total.integrate_ms) total.integrate_ms = ms[1];
+            if (ms[2] > total.epilogue_ms) total.epilogue_ms = ms[2];
+        }
+    }
+    if (stats) *stats = total;
     return LT_OK;
 }
 
@@ -635,47 +954,47 @@ static int trace_batch(const MetricConsts &mc, lt_opts &o, double lambda_max, co
     if (mc.kind == LT_METRIC_KERR && !thetas) return fail(LT_ERR_INVALID_ARG, "Kerr needs thetas");
     int64_t n_q = (n + 63) / 64 * 64;
     size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
-    Workspace w;
-    if ((rc = get_workspace((size_t)n_q, elem, &w))) return rc;
-    void *ic = w.ic, *fin0 = w.fin0, *fin1 = w.fin1;
+    // The twins are synchronous calls on the default stream, like the reference's ("no async").  Records
+    // and staging buffers belong to the (device, default stream) slot, so they never alias what an lt_render_dev
+    // call on another stream is using, and nothing is allocated per call once they have grown.
     hipStream_t s = nullptr;
-    DevBuf dal, dth, dref, dfa, dw, dst, dev;
-    if ((rc = dal.alloc(n * 8))) return rc;
-    HIP_TRY(hipMemcpyAsync(dal.p, alphas, n * 8, hipMemcpyHostToDevice, s));
-    if (thetas) {
-        if ((rc = dth.alloc(n * 8))) return rc;
-        HIP_TRY(hipMemcpyAsync(dth.p, thetas, n * 8, hipMemcpyHostToDevice, s));
-    }
-    if (refines) {
-        if ((rc = dref.alloc(n))) return rc;
-        HIP_TRY(hipMemcpyAsync(dref.p, refines, n, hipMemcpyHostToDevice, s));
-    }
-    if ((rc = dfa.alloc(n * 8)) || (rc = dw.alloc(n * 8))) return rc;
-    if (out_status && (rc = dst.alloc(n))) return rc;
-    if (out_evals && (rc = dev.alloc(n * 4))) return rc;
+    Workspace w;
+    if ((rc = get_workspace(s, (size_t)n_q, elem, &w))) return rc;
+    void *ic = w.ic, *fin0 = w.fin0, *fin1 = w.fin1;
+    StreamSlot *sl;
+    if ((rc = get_slot(s, &sl))) return rc;
+    Carver cv;
+    size_t o_al = cv.take(n * 8), o_th = thetas ? cv.take(n * 8) : 0, o_ref = refines ? cv.take(n) : 0;
+    size_t o_fa = cv.take(n * 8), o_w = cv.take(n * 8), o_st = out_status ? cv.take(n) : 0, o_ev = out_evals ? cv.take(n * 4) : 0;
+    if ((rc = grow(sl->dev, cv.off, s))) return rc;
+    char *base = (char *)sl->dev.p;
+    const double *d_al = (const double *)(base + o_al);
+    const double *d_th = thetas ? (const double *)(base + o_th) : nullptr;
+    const uint8_t *d_ref = refines ? (const uint8_t *)(base + o_ref) : nullptr;
+    double *d_fa = (double *)(base + o_fa);
+    int64_t *d_w = (int64_t *)(base + o_w);
+    int8_t *d_st = out_status ? (int8_t *)(base + o_st) : nullptr;
+    uint32_t *d_ev = out_evals ? (uint32_t *)(base + o_ev) : nullptr;
+    HIP_TRY(hipMemcpyAsync((void *)d_al, alphas, n * 8, hipMemcpyHostToDevice, s));
+    if (thetas) HIP_TRY(hipMemcpyAsync((void *)d_th, thetas, n * 8, hipMemcpyHostToDevice, s));
+    if (refines) HIP_TRY(hipMemcpyAsync((void *)d_ref, refines, n, hipMemcpyHostToDevice, s));
     unsigned gq = (unsigned)((n_q + 255) / 256);
-    if (o.precision == 32)
-        k_prologue_arrays<float><<<gq, 256, 0, s>>>(mc, (const double *)dal.p, (const double *)dth.p,
-                                                    (const uint8_t *)dref.p, n, (float4 *)ic, n_q);
-    else
-        k_prologue_arrays<double><<<gq, 256, 0, s>>>(mc, (const double *)dal.p, (const double *)dth.p,
-                                                     (const uint8_t *)dref.p, n, (double4 *)ic, n_q);
+    if (o.precision == 32) k_prologue_arrays<float><<<gq, 256, 0, s>>>(mc, d_al, d_th, d_ref, n, (float4 *)ic, n_q);
+    else k_prologue_arrays<double><<<gq, 256, 0, s>>>(mc, d_al, d_th, d_ref, n, (double4 *)ic, n_q);
     HIP_TRY(hipGetLastError());
-    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, w, n_q, s)
-                           : launch_integrate<double>(mc, o, lambda_max, w, n_q, s);
+    rc = o.precision == 32 ? launch_integrate<float>(mc, o, lambda_max, w, n_q, s, nullptr)
+                           : launch_integrate<double>(mc, o, lambda_max, w, n_q, s, nullptr);
     if (rc) return rc;
     unsigned gn = (unsigned)((n + 255) / 256);
     if (o.precision == 32)
-        k_epilogue_arrays<float><<<gn, 256, 0, s>>>(mc, (const float4 *)fin0, (const float4 *)fin1, n, (double *)dfa.p,
-                                                    (int64_t *)dw.p, (int8_t *)dst.p, (uint32_t *)dev.p);
+        k_epilogue_arrays<float><<<gn, 256, 0, s>>>(mc, (const float4 *)fin0, (const float4 *)fin1, n, d_fa, d_w, d_st, d_ev);
     else
-        k_epilogue_arrays<double><<<gn, 256, 0, s>>>(mc, (const double4 *)fin0, (const double4 *)fin1, n, (double *)dfa.p,
-                                                     (int64_t *)dw.p, (int8_t *)dst.p, (uint32_t *)dev.p);
+        k_epilogue_arrays<double><<<gn, 256, 0, s>>>(mc, (const double4 *)fin0, (const double4 *)fin1, n, d_fa, d_w, d_st, d_ev);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_fa, dfa.p, n * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(out_w, dw.p, n * 8, hipMemcpyDeviceToHost, s));
-    if (out_status) HIP_TRY(hipMemcpyAsync(out_status, dst.p, n, hipMemcpyDeviceToHost, s));
-    if (out_evals) HIP_TRY(hipMemcpyAsync(out_evals, dev.p, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_fa, d_fa, n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(out_w, d_w, n * 8, hipMemcpyDeviceToHost, s));
+    if (out_status) HIP_TRY(hipMemcpyAsync(out_status, d_st, n, hipMemcpyDeviceToHost, s));
+    if (out_evals) HIP_TRY(hipMemcpyAsync(out_evals, d_ev, n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return LT_OK;
 }
@@ -754,6 +1073,9 @@ extern "C" int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t hei
     return LT_OK;
 }
 
+#ifdef LT_PROBES
+// Diagnostic microbenchmarks (tools/issue_probe.py, lone_step.py ...): compiled only into the probe build
+// (`python __graft_entry__.py --probes` -> lib/libltrace_probes.so), never into the product library.
 extern "C" int lt_valu_peak_probe(int mode, int iters, double *tflops)
 {
     int rc = require_device();
@@ -914,6 +1236,8 @@ extern "C" int lt_piece_probe(int piece, int waves_per_simd, int iters, double *
     if (cycles_per_eval) *cycles_per_eval = (double)ms * 1e-3 * mhz * 1e6 / ((double)iters * 4.0 * waves_per_simd);
     return LT_OK;
 }
+
+#endif // LT_PROBES
 
 #include "lt_api_stages.inc"
 #include "lt_api_dense.inc"

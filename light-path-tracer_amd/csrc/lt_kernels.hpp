@@ -286,6 +286,39 @@ __device__ __forceinline__ void write_stamp(uint4 *stamps, int64_t wave, uint64_
     }
 }
 
+// Work and clock accounting of the integrate kernels (LT_STAT_WAVE_ITERS .. LT_STAT_CLK_TICKS of the
+// caller's counters; kstats == NULL: nothing).  One no-return atomic per wavefront for the iteration
+// count -- the unit the executed-instruction roofline of bench.py is priced in -- and, on every 64th
+// wavefront, the shader-clock cycles and 100 MHz real-time ticks of its lifetime, so that the clock
+// the chip actually held during the launch (it lowers it under VALU-dense load) can be reported.
+// Never read by any kernel; no output value depends on it.
+struct WaveMeter {
+    uint64_t c0 = 0, r0 = 0;
+    bool sample = false;
+    __device__ __forceinline__ void begin(const uint64_t *kstats, int64_t wave)
+    {
+        // (readfirstlane: the wave index is wave-uniform, but only this tells the compiler, so that the stamps
+        // live in SGPRs instead of four VGPRs held across the whole kernel)
+        sample = kstats && (__builtin_amdgcn_readfirstlane((uint32_t)wave) & 63u) == 0u;
+        if (sample) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    }
+    __device__ __forceinline__ void end(uint64_t *kstats, uint32_t wave_iters)
+    {
+        if (!kstats) return;
+        // max over the wave: lanes that finished early stopped counting
+        uint32_t m = wave_iters;
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+        if ((threadIdx.x & 63) != 0) return;
+        atomicAdd((unsigned long long *)&kstats[6], (unsigned long long)m);
+        atomicAdd((unsigned long long *)&kstats[7], 1ull);
+        if (sample) {
+            uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+            atomicAdd((unsigned long long *)&kstats[8], (unsigned long long)(c1 - c0));
+            atomicAdd((unsigned long long *)&kstats[9], (unsigned long long)(r1 - r0));
+        }
+    }
+};
+
 // ---- K2: integrate --------------------------------------------------------------------------
 // Final record: fin0 = (r, theta, phi, p_r), fin1 = (p_theta, p_phi, event, steps)   [Kerr]
 //               fin0 = (u, w, phi_last, full_steps), fin1 = (0, 0, event, steps)      [Schwarzschild]
@@ -305,11 +338,14 @@ template <typename T, typename Integ>
 __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
-                                                         uint32_t long_iters, uint4 *__restrict__ stamps)
+                                                         uint32_t long_iters, uint4 *__restrict__ stamps,
+                                                         uint64_t *__restrict__ kstats)
 {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
     uint64_t t0 = stamps ? wave_clock() : 0;
+    WaveMeter meter;
+    meter.begin(kstats, q >> 6);
     KerrConsts<T> k = k_in;
     pin_consts(k);
     typename Vec4<T>::type rec = ic[q];
@@ -318,6 +354,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
     st.y.r = k.r_obs; st.y.th = k.theta_obs; st.y.ph = T(0); st.y.pr = rec.x; st.y.pth = rec.y;
     st.steps = 0;
     int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
+    uint32_t wave_iters = 0; // wave-uniform: loop iterations this wave issued (streak attempts + general iterations)
     if (flags & FLAG_OK) {
         RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
         Integ::start(k, rc, st, rec.x, rec.y);
@@ -331,9 +368,12 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
             ev = Integ::advance(k, rc, st);
             if (++it >= long_iters && !raised) { __builtin_amdgcn_s_setprio(3); raised = true; }
         } while (ev == EV_RUNNING);
+        // lanes leave the loop one by one; the last one out has counted every iteration the wave issued
+        wave_iters = it;
     }
     uint32_t steps = st.steps;
     store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
+    meter.end(kstats, wave_iters);
     if (stamps) write_stamp(stamps, q >> 6, t0, steps);
 }
 
@@ -349,18 +389,24 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
 template <typename T, typename Integ>
 __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                         typename Vec4<T>::type *__restrict__ fin0,
-                                                        typename Vec4<T>::type *__restrict__ fin1, uint32_t n_q,
-                                                        uint32_t *__restrict__ head, uint32_t chunk,
+                                                        typename Vec4<T>::type *__restrict__ fin1, uint64_t n_q,
+                                                        unsigned long long *__restrict__ head, uint32_t chunk,
                                                         uint32_t refill_min, uint32_t long_steps,
-                                                        uint4 *__restrict__ stamps)
+                                                        uint4 *__restrict__ stamps, uint64_t *__restrict__ kstats)
 {
     uint64_t t0 = stamps ? wave_clock() : 0;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    WaveMeter meter;
+    meter.begin(kstats, wave_id);
     KerrConsts<T> k = k_in;
     pin_consts(k);
-    uint32_t next = 0, end = 0; // wave-uniform: this wave's chunk
+    // the queue head is 64-bit: every wave adds one more chunk after the queue has drained, so a 32-bit head
+    // could wrap for n_q within (waves x chunk) of 2^32
+    uint64_t next = 0, end = 0; // wave-uniform: this wave's chunk
     bool drained = false;       // wave-uniform: the global queue is empty
     bool have = false;          // this lane holds a live ray
-    uint32_t q = 0, total_steps = 0;
+    uint64_t q = 0;
+    uint32_t total_steps = 0, wave_iters = 0;
     int prio = 0;
     typename Integ::State st;
     RayConsts<T> rc = make_ray_consts(k, T(0), false);
@@ -372,9 +418,10 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
             // ---- refill idle lanes from the wave's chunk; reserve a new chunk when it runs out
             for (;;) {
                 if (next >= end) {
-                    uint32_t base = 0;
-                    if ((threadIdx.x & 63) == 0) base = atomicAdd(head, chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
+                    unsigned long long base = 0;
+                    if ((threadIdx.x & 63) == 0) base = atomicAdd(head, (unsigned long long)chunk);
+                    base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+                           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
                     if (base >= n_q) { drained = true; break; }
                     next = base;
                     end = (n_q - base < chunk) ? n_q : base + chunk;
@@ -383,7 +430,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
                 n_idle = (uint32_t)__popcll(idle);
                 if (!n_idle) break;
                 uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-                uint32_t avail = end - next;
+                uint32_t avail = (uint32_t)(end - next);
                 if (!have && rank < avail) {
                     q = next + rank;
                     typename Vec4<T>::type rec = ic[q];
@@ -407,8 +454,9 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
         if (have) {
             // a far-field streak only while nothing is waiting for it to end: every lane busy (fewer idle lanes than
             // the refill threshold) or the queue drained
-            if (n_idle < refill_min || drained) Integ::streak(k, rc, st, 16u);
+            if (n_idle < refill_min || drained) wave_iters += Integ::streak(k, rc, st, 16u);
             int ev = Integ::advance(k, rc, st);
+            ++wave_iters;
             if (ev != EV_RUNNING) {
                 store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
                 total_steps += st.steps;
@@ -421,7 +469,8 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
             if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
         }
     }
-    if (stamps) write_stamp(stamps, (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), t0, total_steps);
+    meter.end(kstats, wave_iters);
+    if (stamps) write_stamp(stamps, wave_id, t0, total_steps);
 }
 
 template <typename T>
@@ -690,6 +739,7 @@ __global__ void k_kerr_rhs_probe(KerrConsts<T> k, const double *__restrict__ sta
     out[i * 5 + 0] = dr; out[i * 5 + 1] = dth; out[i * 5 + 2] = dph; out[i * 5 + 3] = dpr; out[i * 5 + 4] = dpth;
 }
 
+#ifdef LT_PROBES
 // Issue-efficiency probe: the RK4 step alone -- no events, no divergence, no refill -- iterated on
 // every lane.  Comparing its cycles per step with the integrate kernel's separates what the
 // arithmetic costs from what the control flow around it costs (lt_rk4_step_probe).
@@ -718,6 +768,8 @@ __global__ void __launch_bounds__(256) k_probe_rk4_step(KerrConsts<T> k_in, int 
     }
 }
 
+#endif // LT_PROBES
+
 // Row scatter after the multi-GPU gather: partition rows -> full frame, 16 B per lane where possible.
 __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__restrict__ full, int rows_local,
                                int64_t row_bytes, int row_block, int n_parts, int part_id)
@@ -736,6 +788,7 @@ __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__rest
     }
 }
 
+#ifdef LT_PROBES
 // FP32 VALU issue-rate probe: 8 independent FMA chains per lane.
 __global__ void __launch_bounds__(256) k_valu_probe(int mode, int iters, float *sink)
 {
@@ -776,5 +829,7 @@ __global__ void __launch_bounds__(256) k_valu_probe(int mode, int iters, float *
         if (s.x + s.y == 12345.678f) sink[0] = s.x;
     }
 }
+
+#endif // LT_PROBES
 
 } // namespace lt

@@ -18,7 +18,8 @@ METRIC_SCHWARZSCHILD, METRIC_KERR = 0, 1
 INTEGRATOR_DP45, INTEGRATOR_RK4 = 0, 1
 SCHED_DIRECT, SCHED_QUEUE = 0, 1
 STAT_RAYS, STAT_STEPS, STAT_RHS_EVALS, STAT_ESCAPED, STAT_CAPTURED, STAT_INVALID = range(6)
-STAT_WORDS = 8
+STAT_WAVE_ITERS, STAT_WAVES, STAT_CLK_CYCLES, STAT_CLK_TICKS = 6, 7, 8, 9
+STAT_WORDS = 16
 
 INTEGRATORS = {"dp45": INTEGRATOR_DP45, "rk4": INTEGRATOR_RK4}
 SCHEDULES = {"direct": SCHED_DIRECT, "queue": SCHED_QUEUE}
@@ -70,6 +71,12 @@ _lib = None
 # name -> (restype, argtypes); every symbol include/ltrace.h declares
 SIGNATURES = {
     "lt_version": (C.c_int, []),
+    "lt_build_id": (C.c_char_p, []),
+    "lt_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "lt_host_free": (C.c_int, [C.c_void_p]),
+    "lt_render_multi": (C.c_int, [C.POINTER(Camera), C.POINTER(Metric), C.POINTER(Opts), C.c_int32, C.c_void_p,
+                                  C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.POINTER(Stats)]),
     "lt_last_error": (C.c_char_p, []),
     "lt_device_count": (C.c_int, []),
     "lt_set_device": (C.c_int, [C.c_int]),
@@ -100,11 +107,6 @@ SIGNATURES = {
     "lt_integrate_dense_dev": (C.c_int, [C.POINTER(Metric), C.POINTER(DenseOpts), C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lt_rhs8_probe": (C.c_int, [C.POINTER(Metric), C.c_void_p, C.c_int64, C.c_void_p]),
-    "lt_valu_peak_probe": (C.c_int, [C.c_int, C.c_int, _dp]),
-    "lt_valu_issue_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, _dp, _dp]),
-    "lt_valu_issue_probe_count": (C.c_int, []),
-    "lt_rk4_step_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp]),
-    "lt_piece_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp]),
 }
 
 
@@ -224,34 +226,88 @@ def global_rows(height, row_block, n_parts, part):
     return np.array([lib.lt_global_row(i, row_block, n_parts, part) for i in range(n)], dtype=np.int64)
 
 
+# ---- pinned output arrays -----------------------------------------------------------------------------
+# lt_render writes a destination that lies in pinned host memory by DMA straight from the device; a pageable
+# numpy array costs an extra pass through the library's staging area.  render() therefore hands out arrays
+# backed by lt_host_alloc blocks.  Blocks are recycled by size once the last numpy view of them is gone
+# (allocating pinned memory costs milliseconds, a 4096^2 frame every call).
+import weakref
+
+_pinned_free = {}     # nbytes -> [address, ...]
+_PINNED_POOL_LIMIT = int(os.environ.get("LTRACE_PINNED_POOL_MB", "2048")) << 20
+_pinned_pooled = 0
+
+
+def _pinned_release(addr, nbytes):
+    global _pinned_pooled
+    if _lib is None:
+        return
+    if _pinned_pooled + nbytes <= _PINNED_POOL_LIMIT:
+        _pinned_free.setdefault(nbytes, []).append(addr)
+        _pinned_pooled += nbytes
+    else:
+        _lib.lt_host_free(C.c_void_p(addr))
+
+
+def pinned_empty(shape, dtype):
+    """numpy array of `shape` / `dtype` in pinned host memory (lt_host_alloc); freed or recycled when the array
+    and all its views are gone.  Falls back to ordinary memory for empty arrays."""
+    global _pinned_pooled
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype=dtype)
+    nbytes = (nbytes + 4095) & ~4095
+    lst = _pinned_free.get(nbytes)
+    if lst:
+        addr = lst.pop()
+        _pinned_pooled -= nbytes
+    else:
+        addr = load().lt_host_alloc(nbytes)
+        if not addr:
+            raise LtraceError(ERR_HIP, load().lt_last_error().decode("utf-8", "replace"))
+    buf = (C.c_ubyte * nbytes).from_address(addr)
+    weakref.finalize(buf, _pinned_release, addr, nbytes).atexit = False   # at exit the process frees it
+    n = int(np.prod(shape, dtype=np.int64))
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
+def _frame_outputs(rows, W, nch, gray, want):
+    out = {}
+    if "fa" in want:
+        out["fa"] = pinned_empty((rows, W), np.float32)
+    if "winding" in want:
+        out["winding"] = pinned_empty((rows, W), np.uint16)
+    if "status" in want:
+        out["status"] = pinned_empty((rows, W), np.int8)
+    if "steps" in want:
+        out["steps"] = pinned_empty((rows, W), np.uint32)
+    if "rgb" in want:
+        out["rgb"] = pinned_empty((rows, W) if gray else (rows, W, nch), np.float32)
+    if "rgba" in want:
+        out["rgba"] = pinned_empty((rows, W, 4), np.uint8)
+    return out
+
+
+def _background(cam, background):
+    if background is None:
+        return None, 3, False
+    bg = np.ascontiguousarray(background, dtype=np.float32)
+    if bg.shape[:2] != (cam.height, cam.width):
+        raise ValueError("background must have the frame's height and width")
+    nch = 1 if bg.ndim == 2 else bg.shape[2]
+    if nch not in (1, 3):
+        raise ValueError("background must be grayscale or RGB")
+    return bg, nch, bg.ndim == 2
+
+
 def render(cam, metric, opts, background=None, want=("fa", "winding", "status", "steps", "rgb", "rgba")):
-    """Host-pointer frame render (lt_render).  Returns dict of numpy arrays + 'stats'."""
+    """Host-pointer frame render (lt_render).  Returns dict of numpy arrays (pinned memory) + 'stats'."""
     rows = local_rows(cam.height, opts.row_block or 16, opts.n_parts or 1, opts.part)
     if rows < 0 or cam.width <= 0:
         raise LtraceError(ERR_INVALID_ARG, f"bad frame {cam.width}x{cam.height} or partition {opts.part}/{opts.n_parts}")
-    W = cam.width
-    bg = None
-    nch = 3
-    if background is not None:
-        bg = np.ascontiguousarray(background, dtype=np.float32)
-        if bg.shape[:2] != (cam.height, cam.width):
-            raise ValueError("background must have the frame's height and width")
-        nch = 1 if bg.ndim == 2 else bg.shape[2]
-        if nch not in (1, 3):
-            raise ValueError("background must be grayscale or RGB")
-    out = {}
-    if "fa" in want:
-        out["fa"] = np.empty((rows, W), dtype=np.float32)
-    if "winding" in want:
-        out["winding"] = np.empty((rows, W), dtype=np.uint16)
-    if "status" in want:
-        out["status"] = np.empty((rows, W), dtype=np.int8)
-    if "steps" in want:
-        out["steps"] = np.empty((rows, W), dtype=np.uint32)
-    if "rgb" in want:
-        out["rgb"] = np.empty((rows, W) if (bg is not None and bg.ndim == 2) else (rows, W, nch), dtype=np.float32)
-    if "rgba" in want:
-        out["rgba"] = np.empty((rows, W, 4), dtype=np.uint8)
+    bg, nch, gray = _background(cam, background)
+    out = _frame_outputs(rows, cam.width, nch, gray, want)
     st = Stats()
     _check(load().lt_render(C.byref(cam), C.byref(metric), C.byref(opts), _np_ptr(bg), nch,
                             _np_ptr(out.get("fa")), _np_ptr(out.get("winding")), _np_ptr(out.get("status")),
@@ -259,6 +315,29 @@ def render(cam, metric, opts, background=None, want=("fa", "winding", "status", 
                             C.byref(st)))
     out["stats"] = stats_dict(st.counters, st.prologue_ms, st.integrate_ms, st.epilogue_ms)
     return out
+
+
+def render_multi(cam, metric, opts, n_gpus, devices=None, background=None,
+                 want=("fa", "winding", "status", "steps", "rgb", "rgba")):
+    """One frame on `n_gpus` devices of this node from this one process (lt_render_multi): full-frame arrays."""
+    bg, nch, gray = _background(cam, background)
+    out = _frame_outputs(cam.height, cam.width, nch, gray, want)
+    dv = None
+    if devices is not None:
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        if dv.size != n_gpus:
+            raise ValueError("devices must list one device per partition")
+    st = Stats()
+    _check(load().lt_render_multi(C.byref(cam), C.byref(metric), C.byref(opts), int(n_gpus), _np_ptr(dv), _np_ptr(bg), nch,
+                                  _np_ptr(out.get("fa")), _np_ptr(out.get("winding")), _np_ptr(out.get("status")),
+                                  _np_ptr(out.get("steps")), _np_ptr(out.get("rgb")), _np_ptr(out.get("rgba")),
+                                  C.byref(st)))
+    out["stats"] = stats_dict(st.counters, st.prologue_ms, st.integrate_ms, st.epilogue_ms)
+    return out
+
+
+def build_id():
+    return load().lt_build_id().decode()
 
 
 def pixel_angles(cam, axis_refine_frac=0.07, want_theta=True):
@@ -333,8 +412,10 @@ def rhs8_probe(metric, states):
 
 def stats_dict(counters, prologue_ms=0.0, integrate_ms=0.0, epilogue_ms=0.0):
     c = [int(x) for x in counters]
+    clk = c[STAT_CLK_CYCLES] / c[STAT_CLK_TICKS] * 100.0 if c[STAT_CLK_TICKS] else 0.0   # ticks are 100 MHz
     return dict(rays=c[STAT_RAYS], steps=c[STAT_STEPS], rhs_evals=c[STAT_RHS_EVALS], escaped=c[STAT_ESCAPED],
-                captured=c[STAT_CAPTURED], invalid=c[STAT_INVALID],
+                captured=c[STAT_CAPTURED], invalid=c[STAT_INVALID], wave_iters=c[STAT_WAVE_ITERS],
+                waves=c[STAT_WAVES], clock_mhz=clk,
                 prologue_ms=prologue_ms, integrate_ms=integrate_ms, epilogue_ms=epilogue_ms)
 
 
@@ -359,38 +440,11 @@ def timing_collect():
     return dict(prologue_ms=a.value, integrate_ms=b.value, epilogue_ms=c.value, calls=n.value)
 
 
-def valu_peak_probe(mode=0, iters=4096):
-    t = C.c_double()
-    _check(load().lt_valu_peak_probe(mode, iters, C.byref(t)))
-    return t.value
-
-
-def valu_issue_probe(index, waves_per_simd=8, iters=2000, constant_data=False):
-    """-> (mnemonic, ns per wave-instruction per SIMD, shader clock in MHz during the loop)"""
-    name = C.create_string_buffer(64)
-    t, clk = C.c_double(), C.c_double()
-    _check(load().lt_valu_issue_probe(index, waves_per_simd, iters, int(constant_data), name, 64,
-                                      C.byref(t), C.byref(clk)))
-    return name.value.decode(), t.value, clk.value
-
-
-def rk4_step_probe(precision=32, waves_per_simd=8, iters=20000):
-    """-> (shader cycles one SIMD spends per wave-step of the bare Kerr RK4 step, clock MHz)"""
-    c, clk = C.c_double(), C.c_double()
-    _check(load().lt_rk4_step_probe(precision, waves_per_simd, iters, C.byref(c), C.byref(clk)))
-    return c.value, clk.value
-
-
-def piece_probe(piece, waves_per_simd=8, iters=20000):
-    c, clk = C.c_double(), C.c_double()
-    _check(load().lt_piece_probe(piece, waves_per_simd, iters, C.byref(c), C.byref(clk)))
-    return c.value, clk.value
-
-
-def valu_issue_probe_count():
-    return int(load().lt_valu_issue_probe_count())
-
-
 def shutdown():
     if _lib is not None:
         _lib.lt_shutdown()
+        for nbytes, lst in _pinned_free.items():
+            for addr in lst:
+                _lib.lt_host_free(C.c_void_p(addr))
+        _pinned_free.clear()
+        globals()['_pinned_pooled'] = 0

@@ -74,6 +74,29 @@ def lib():
     return _LIB
 
 
+_LIB_PERF = None
+PERF_FLAGS = ["-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11"]
+
+
+def lib_perf():
+    """The same lt_oracle.c compiled for speed on THIS machine (-O3 -march=native, FMA contraction allowed), into a
+    temporary directory: the timing build of bench.py's cpu_baseline leg.  Never used for parity --
+    the parity build above is -O2 -ffp-contract=off -- and never shipped: -march=native code is only valid on
+    the host that compiled it."""
+    global _LIB_PERF
+    if _LIB_PERF is None:
+        import tempfile
+        d = tempfile.mkdtemp(prefix="lt_oracle_perf_")
+        so = os.path.join(d, "liblt_oracle_perf.so")
+        subprocess.check_call(["gcc"] + PERF_FLAGS + ["-o", so, os.path.join(_HERE, "lt_oracle.c"), "-lm"])
+        L = C.CDLL(so)
+        L.lto_lookup.argtypes = lib().lto_lookup.argtypes
+        L.lto_lookup.restype = C.c_int64
+        L.lto_num_threads.restype = C.c_int
+        _LIB_PERF = L
+    return _LIB_PERF
+
+
 def lib32():
     global _LIB32
     if _LIB32 is None:
@@ -168,13 +191,14 @@ def pixel_angles(H, W, hfov, vfov, psi=(0.0, 0.0), axis_refine_frac=0.07):
 
 
 def lookup(kind, M, a, r_obs, H, W, hfov, vfov, psi=(0.0, 0.0), theta_obs=np.pi / 2,
-           integrator="dp45", tb_symmetry=False, axis_refine_frac=0.07):
-    """Per-pixel trace of a whole frame -> dict(fa f32, winding u16, status i8, evals u32, traced)."""
+           integrator="dp45", tb_symmetry=False, axis_refine_frac=0.07, perf_build=False):
+    """Per-pixel trace of a whole frame -> dict(fa f32, winding u16, status i8, evals u32, traced).
+    perf_build: run the -O3 -march=native build (timing only, see lib_perf)."""
     fa = np.empty((H, W), dtype=np.float32)
     w = np.empty((H, W), dtype=np.uint16)
     st = np.empty((H, W), dtype=np.int8)
     ev = np.empty((H, W), dtype=np.uint32)
-    traced = lib().lto_lookup(0 if kind == "schwarzschild" else 1, M, a, r_obs, theta_obs, H, W,
+    traced = (lib_perf() if perf_build else lib()).lto_lookup(0 if kind == "schwarzschild" else 1, M, a, r_obs, theta_obs, H, W,
                               hfov, vfov, psi[0], psi[1], axis_refine_frac,
                               0 if integrator == "dp45" else 1, int(bool(tb_symmetry)),
                               _ptr(fa, _fp), _ptr(w, C.POINTER(C.c_uint16)),

@@ -263,17 +263,34 @@ def test_partitions_reassemble_bit_identically():
             assert np.array_equal(acc[k], whole[k], equal_nan=True), k
 
 
+def _subsample_vs_oracle(out, small, k, p99, flips_budget=66):
+    sub_fa, sub_st = out["fa"][::k, ::k], out["status"][::k, ::k]
+    flips = (sub_st == 1) != (small["status"] == 1)
+    assert flips.sum() <= flips_budget, f"{flips.sum()} escaped/not flips in the subsample"
+    both = (sub_st == 1) & (small["status"] == 1)
+    d = np.abs(sub_fa[both].astype(np.float64) - small["fa"][both])
+    assert np.median(d) <= 5e-6 and np.quantile(d, 0.99) <= p99, (np.median(d), np.quantile(d, 0.99))
+
+
 @pytest.mark.parametrize("size", [2048])
 def test_kerr_large_frame_properties(size):
-    """BASELINE config 3 shape (Kerr a=0.9, float32) at full size, through size-independent
-    properties: every pixel accounted for; shadow fraction and mean step count match the oracle's
-    at 256^2 (they are resolution independent); north/south mirror symmetry of the equatorial
-    observer; a strided subsample equals the oracle within the float32 budget."""
+    """BASELINE config 3 (Kerr a=0.9 2048^2, float32, "wavefront ray-compaction") at full size, BOTH schedules:
+    the persistent ray-queue kernel (atomic chunk reservation, ballot refill) and the direct kernel must agree
+    byte for byte at this size too; then size-independent properties: every pixel accounted for; shadow
+    fraction and mean step count match the oracle's at 256^2 (they are resolution independent); north/south
+    mirror symmetry of the equatorial observer; a strided subsample equals the oracle within the float32 budget."""
     cam = _cam(size, size, 50.0)
     met = ltrace.Metric(1, 0, 1.0, 0.9)
-    out = ltrace.render(cam, met, ltrace.default_opts(precision=32), want=("fa", "status", "steps"))
+    out = ltrace.render(cam, met, ltrace.default_opts(precision=32, schedule="direct"), want=("fa", "status", "steps", "winding"))
+    que = ltrace.render(cam, met, ltrace.default_opts(precision=32, schedule="queue"), want=("fa", "status", "steps", "winding"))
+    for k in ("fa", "status", "steps", "winding"):
+        assert np.array_equal(out[k], que[k], equal_nan=True), f"queue schedule differs from direct in {k} at {size}^2"
+    for k in ("rays", "steps", "rhs_evals", "escaped", "captured", "invalid"):
+        assert out["stats"][k] == que["stats"][k], k
     st = out["stats"]
     assert st["rays"] == size * size == st["escaped"] + st["captured"] + st["invalid"]
+    assert st["waves"] == (size // 8) ** 2 and st["wave_iters"] >= out["steps"].max()     # the kernel's own work counters
+    assert 500.0 < st["clock_mhz"] < 2600.0
     small = oracle.lookup("kerr", 1.0, 0.9, 50.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
     frac_small = (small["status"] != 1).mean()
     frac_big = (out["status"] != 1).mean()
@@ -283,13 +300,31 @@ def test_kerr_large_frame_properties(size):
     up, down = esc[1:size // 2], esc[size // 2 + 1:][::-1]       # row j <-> row H - j
     assert (up != down).mean() < 1e-3
     # strided subsample: pixels (8i, 8j) of the 2048 frame are pixels (i, j) of a 256 frame
-    k = size // 256
-    sub_fa, sub_st = out["fa"][::k, ::k], out["status"][::k, ::k]
-    flips = (sub_st == 1) != (small["status"] == 1)
-    assert flips.sum() <= 66
-    both = (sub_st == 1) & (small["status"] == 1)
-    d = np.abs(sub_fa[both].astype(np.float64) - small["fa"][both])
-    assert np.median(d) <= 5e-6 and np.quantile(d, 0.99) <= 5e-5
+    _subsample_vs_oracle(out, small, size // 256, 5e-5)
+
+
+def test_north_star_frame_4096():
+    """THE benchmark frame (BASELINE.json metric: Kerr a = 0.9, 4096^2, r_obs = 50 M, fixed-step RK4 float32) at
+    full size: every 16th pixel against the oracle's 256^2 frame of the same camera (float32 budget), class
+    counts against the oracle's class fractions, and the queue schedule's counters against the direct one's."""
+    size = 4096
+    cam = _cam(size, size, 50.0)
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    out = ltrace.render(cam, met, ltrace.default_opts(precision=32), want=("fa", "status"))
+    st = out["stats"]
+    assert st["rays"] == size * size == st["escaped"] + st["captured"] + st["invalid"]
+    small = oracle.lookup("kerr", 1.0, 0.9, 50.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
+    _subsample_vs_oracle(out, small, 16, 5e-5)
+    # class fractions are resolution independent up to the pixels the critical curve crosses (~ perimeter / area)
+    for name, code in (("escaped", 1), ("captured", -1)):
+        assert abs(st[name] / st["rays"] - (small["status"] == code).mean()) < 2e-3, name
+    assert st["invalid"] / st["rays"] < 1e-3
+    # 154.7 steps per ray in float32 (bench line), 618.8 / 4 in the float64 oracle
+    assert abs(st["steps"] / st["rays"] - small["evals"].mean() / 4) < 0.01 * small["evals"].mean() / 4
+    q = ltrace.render(cam, met, ltrace.default_opts(precision=32, schedule="queue"), want=("status",))
+    for k in ("rays", "steps", "escaped", "captured", "invalid"):
+        assert q["stats"][k] == st[k], k
+    assert np.array_equal(q["status"], out["status"])
 
 
 @pytest.mark.parametrize("precision", [32, 64])
@@ -398,6 +433,11 @@ def test_image_lens_4096_lensed_background():
     assert np.all(out["rgb"][out["status"] != 1] == 0)           # captured / invalid -> black
     # corners: deflection ~ 4M/b is a few pixels there, never the identity, never out of frame by much
     assert out["stats"]["rays"] == n * n and (out["status"] == 1).mean() > 0.97
+    # and the lookup itself: every 16th pixel against the oracle's 256^2 frame of the same camera (r_obs = 100 M:
+    # twice the steps per ray of the r_obs = 50 frames, so rounding accumulates further; p99 budget 1e-4, stated)
+    small = oracle.lookup("kerr", 1.0, 0.9, 100.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
+    _subsample_vs_oracle(out, small, 16, 1e-4)
+    assert abs(out["stats"]["steps"] / out["stats"]["rays"] - small["evals"].mean() / 4) < 0.01 * small["evals"].mean() / 4
 
 
 def test_inclined_observer_and_grayscale_fused():
@@ -568,3 +608,100 @@ def test_random_scenes_match_oracle_in_float64(seed):
     d = np.abs(out["fa"][both].astype(np.float64) - ref["fa"][both])
     assert np.quantile(d, 0.99) <= (2e-7 if integ == "rk4" else 5e-6), (np.quantile(d, 0.99), W, H, a, r_obs, integ)
     assert (out["winding"][both] != ref["winding"][both]).sum() <= max(2, int(2e-4 * n))
+
+
+def test_fused_render_with_loop_around():
+    """render_loop_around (image_lens.py:296-298, :367-375) through the FUSED path: source pixels that leave the frame
+    wrap modulo the image size instead of turning magenta.  An off-axis black hole pushes many sources out of frame."""
+    W, H = 200, 144
+    cam = _cam(W, H, 50.0, psi=(0.15, -0.35))
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    bg = _background(H, W, 7)
+    outs = {}
+    for la in (0, 1):
+        out = ltrace.render(cam, met, ltrace.default_opts(precision=32, loop_around=la), background=bg)
+        img = oracle.render(bg, out["fa"], out["winding"], cam.hfov, cam.vfov, psi=(0.15, -0.35), loop_around=bool(la))
+        assert np.array_equal(out["rgb"], img), f"loop_around={la}"
+        assert np.array_equal(out["rgba"], oracle.rgba8(img))
+        outs[la] = out
+    magenta = np.all(outs[0]["rgb"] == np.float32([1, 0, 1]), axis=-1)
+    assert magenta.sum() > 50                                                  # the case is exercised
+    assert (np.all(outs[1]["rgb"] == np.float32([1, 0, 1]), axis=-1) & magenta).sum() <= magenta.sum() // 50
+    assert np.array_equal(outs[0]["fa"], outs[1]["fa"], equal_nan=True)
+
+
+def test_two_streams_do_not_share_a_workspace():
+    """Concurrency contract of ltrace.h: lt_render_dev calls on DIFFERENT streams of one device own separate ray
+    records (per (device, stream) workspaces), so two frames in flight at once come out as when rendered alone.
+    (Round 1 shared one workspace per device: a second stream overwrote the first frame's records.)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    cams = [_cam(512, 384, 50.0), _cam(448, 512, 50.0, psi=(0.03, 0.1))]
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    alone = []
+    for cam in cams:
+        r = ltrace.render(cam, met, ltrace.default_opts(precision=32), want=("fa", "status", "steps"))
+        alone.append(r)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    bufs = []
+    for rep in range(3):                       # interleave launches: both frames are in flight together
+        bufs = []
+        for cam, s in zip(cams, streams):
+            fa = torch.empty((cam.height, cam.width), dtype=torch.float32, device=dev)
+            stt = torch.empty((cam.height, cam.width), dtype=torch.int8, device=dev)
+            stp = torch.empty((cam.height, cam.width), dtype=torch.int32, device=dev)
+            o = ltrace.default_opts(precision=32)
+            o.stream = s.cuda_stream
+            ltrace.render_dev(cam, met, o, d_fa=fa.data_ptr(), d_status=stt.data_ptr(), d_steps=stp.data_ptr())
+            bufs.append((fa, stt, stp))
+    torch.cuda.synchronize(dev)
+    for (fa, stt, stp), ref in zip(bufs, alone):
+        assert np.array_equal(fa.cpu().numpy(), ref["fa"], equal_nan=True)
+        assert np.array_equal(stt.cpu().numpy(), ref["status"])
+        assert np.array_equal(stp.cpu().numpy().astype(np.uint32), ref["steps"])
+    # a batch trace on the default stream while a frame is in flight on a side stream
+    o = ltrace.default_opts(precision=32)
+    o.stream = streams[0].cuda_stream
+    fa, stt, stp = bufs[0]
+    ltrace.render_dev(cams[0], met, o, d_fa=fa.data_ptr(), d_status=stt.data_ptr(), d_steps=stp.data_ptr())
+    al = np.linspace(0.05, 0.3, 3000)
+    bf, bw = np.full(al.size, np.nan), np.zeros(al.size, dtype=np.int64)
+    ltrace.trace_batch_kerr(1.0, 0.9, 50.0, al, np.full(al.size, 0.7), np.pi / 2, 5000.0, None, bf, bw, precision=32)
+    torch.cuda.synchronize(dev)
+    assert np.array_equal(fa.cpu().numpy(), alone[0]["fa"], equal_nan=True)
+    bf2, bw2 = np.full(al.size, np.nan), np.zeros(al.size, dtype=np.int64)
+    ltrace.trace_batch_kerr(1.0, 0.9, 50.0, al, np.full(al.size, 0.7), np.pi / 2, 5000.0, None, bf2, bw2, precision=32)
+    assert np.array_equal(bf, bf2, equal_nan=True) and np.array_equal(bw, bw2)
+
+
+def test_render_multi_and_host_destinations():
+    """lt_render_multi: partitions rendered concurrently on the listed devices, every device copying its
+    row blocks straight into the caller's full-frame host arrays, equals the single-device frame byte for byte
+    (one GPU here: the partitions queue on device 0).  And lt_render's two destination paths -- pinned (DMA) and
+    pageable (staged pieces + host threads) -- deliver the same bytes."""
+    W, H = 333, 250
+    cam = _cam(W, H, 50.0, psi=(0.02, 0.04))
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    bg = _background(H, W, 9)
+    keys = ("fa", "winding", "status", "steps", "rgb", "rgba")
+    whole = ltrace.render(cam, met, ltrace.default_opts(precision=32), background=bg)
+    for n, rb in ((1, 16), (3, 16), (4, 8)):
+        multi = ltrace.render_multi(cam, met, ltrace.default_opts(precision=32, row_block=rb), n, devices=[0] * n, background=bg)
+        for k in keys:
+            assert np.array_equal(multi[k], whole[k], equal_nan=True), (k, n, rb)
+        for k in ("rays", "steps", "escaped", "captured", "invalid"):
+            assert multi["stats"][k] == whole["stats"][k], (k, n)
+    with pytest.raises(ltrace.LtraceError) as ei:
+        ltrace.render_multi(cam, met, ltrace.default_opts(precision=32), 2, devices=[0, ltrace.device_count()], want=("rgba",))
+    assert ei.value.code == ltrace.ERR_INVALID_ARG
+    # pageable destinations through the C-ABI directly
+    import ctypes as C
+    pg = {"fa": np.empty((H, W), np.float32), "rgba": np.empty((H, W, 4), np.uint8), "steps": np.empty((H, W), np.uint32)}
+    st = ltrace.Stats()
+    o = ltrace.default_opts(precision=32)
+    ltrace._check(ltrace.load().lt_render(C.byref(cam), C.byref(met), C.byref(o), C.c_void_p(bg.ctypes.data), 3,
+                                          C.c_void_p(pg["fa"].ctypes.data), None, None, C.c_void_p(pg["steps"].ctypes.data), None,
+                                          C.c_void_p(pg["rgba"].ctypes.data), C.byref(st)))
+    for k in pg:
+        assert np.array_equal(pg[k], whole[k], equal_nan=True), k
+    assert list(st.counters)[:6] == [whole["stats"][k] for k in ("rays", "steps", "rhs_evals", "escaped", "captured", "invalid")]

@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in ltrace.h but not exported"
     assert declared == set(ltrace.SIGNATURES), "ctypes binding and header disagree"
-    assert ltrace.load().lt_version() == 100
+    assert ltrace.load().lt_version() == 200
+    assert re.fullmatch(r"[0-9a-f]{12}", ltrace.build_id())
 
 
 def test_struct_layouts_match_header():
@@ -39,7 +40,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(ltrace.Camera) == 8 + 6 * 8
     assert ctypes.sizeof(ltrace.Metric) == 8 + 2 * 8
     assert ctypes.sizeof(ltrace.Opts) == 8 * 4 + 3 * 8 + 8 + 8
-    assert ctypes.sizeof(ltrace.Stats) == 8 * 8 + 3 * 8
+    assert ctypes.sizeof(ltrace.Stats) == 16 * 8 + 3 * 8
 
 
 def test_row_partition_is_a_partition():

@@ -2,8 +2,8 @@
 """VALU issue cost table: true cycles (at the measured in-kernel clock) per wave-instruction per SIMD."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "light-path-tracer_amd"))
-import ltrace
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import probes as ltrace   # the diagnostic build (libltrace_probes.so)
 n = ltrace.valu_issue_probe_count()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 print(f"{'instruction':18s} {'data':9s} " + " ".join(f"{'w=' + str(w) + ' cyc':>9s} {'MHz':>6s}" for w in (1, 2, 4, 8)))
