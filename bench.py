@@ -75,6 +75,7 @@ def parse(argv=None):
                     help="skip the untimed extras (end-to-end host-pointer frame, longest-ray chain)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--background", action="store_true", help="image_lens workload: lens a synthetic background")
+    ap.add_argument("--bg-sampling", choices=["lds", "global"], default="lds", help="epilogue background path (LT_BG_*)")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; tests use gloo)")
     ap.add_argument("--stub-render", action="store_true",
                     help="CPU rehearsal of the launcher / gather path: no GPU, rows filled by a formula (tests only)")
@@ -124,28 +125,47 @@ def launch_ranks(args, argv):
 # ------------------------------------------------------------------------------------------------
 # untimed extras
 # ------------------------------------------------------------------------------------------------
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, cut to the cgroup's CPU quota if it has one (a GPU box
+    hands each job a share of a large host: 128 hardware threads visible, 16 usable)."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                n = min(n, max(1, int(int(q) / int(per))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
 def cpu_baseline(args, fov):
-    """Oracle (CPU port of the reference's tracer, float64, all cores), perf build, on a strided subsample of
-    the benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame of the
-    same camera."""
+    """Oracle (CPU port of the reference's tracer, float64, OpenMP), perf build, on a strided subsample of the
+    benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame of the same
+    camera.  One thread per usable CPU."""
+    cores = usable_cpus()
+    os.environ["OMP_NUM_THREADS"] = str(cores)             # before libgomp is first initialised in this process
     from oracle import oracle
     kind = args.metric
+    kw = dict(integrator=args.integrator, perf_build=True)
+    oracle.lookup(kind, 1.0, args.a, args.r_obs, 64, 64, fov, fov, **kw)       # compiles; spins the threads up
     t0 = time.perf_counter()
-    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, integrator=args.integrator, perf_build=True)
-    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, integrator=args.integrator, perf_build=True)
-    dt = (time.perf_counter() - t0) / 2    # calibration (the first call compiles and spins the threads up)
-    rate = 256 * 256 / dt
+    oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, **kw)
+    rate = 256 * 256 / (time.perf_counter() - t0)          # calibration
     stride = 2
     while stride < args.size // 256 and (args.size // stride) ** 2 / rate > args.cpu_seconds:
         stride *= 2
     n = args.size // stride
     t0 = time.perf_counter()
-    r = oracle.lookup(kind, 1.0, args.a, args.r_obs, n, n, fov, fov, integrator=args.integrator, perf_build=True)
+    r = oracle.lookup(kind, 1.0, args.a, args.r_obs, n, n, fov, fov, **kw)
     dt = time.perf_counter() - t0
     return {"value": round(n * n / dt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.num_threads(),
+            "host_cpus_visible": os.cpu_count(),
             "kind": "port (perf build: gcc " + " ".join(oracle.PERF_FLAGS[:3]) + ", built on this host)",
             "sample": f"{n}x{n} rays = every {stride}th pixel (x and y) of the {args.size}x{args.size} frame, "
-                      f"oracle {args.integrator} float64 + OpenMP, {dt:.1f} s",
+                      f"oracle {args.integrator} float64 + OpenMP on {oracle.num_threads()} threads, {dt:.1f} s",
             "mean_rhs_evals_per_ray": round(float(r["evals"].mean()), 1)}
 
 
@@ -311,7 +331,8 @@ def main(argv=None):
 
     stream = torch.cuda.current_stream(dev)
     opts = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
-                               row_block=rb, n_parts=world, part=rank, timing=1)
+                               row_block=rb, n_parts=world, part=rank, timing=1,
+                               bg_sampling=ltrace.BG_LDS_TILES if args.bg_sampling == "lds" else ltrace.BG_GLOBAL)
     opts.stream = stream.cuda_stream
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(args.steps, 1))]   # frame start / rendered / gathered
 
@@ -462,7 +483,9 @@ def main(argv=None):
                        "row_partition": f"block-cyclic {rb} rows x {world}", "gather": "rccl" if world > 1 else "none",
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
-                       "invalid": c[ltrace.STAT_INVALID] // steps},
+                       "invalid": c[ltrace.STAT_INVALID] // steps,
+                       **({"bg_sampling": args.bg_sampling, "bg_groups_lds": c[ltrace.STAT_BG_TILES_LDS] // steps,
+                           "bg_groups_global": c[ltrace.STAT_BG_TILES_GLOBAL] // steps} if args.background else {})},
             "roofline": roof,
             "ranks": {"rccl_world": rccl_world,
                       "integrate_ms": [round(r[1], 3) for r in per_rank],

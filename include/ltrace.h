@@ -80,8 +80,13 @@ typedef struct lt_opts {
     double h_max;            /* Schwarzschild: 0.05 (metrics.py:833); Kerr RK4: 1.0 (metrics.py:677) */
     void *stream;            /* hipStream_t to launch on; NULL = the default stream */
     int32_t timing;          /* !=0: bracket each kernel with HIP events (lt_timing_collect) */
-    int32_t reserved;
+    int32_t bg_sampling;     /* LT_BG_*: how the epilogue reads the background image */
 } lt_opts;
+
+/* background sampling of the epilogue kernel (same texels, bit-identical images) */
+#define LT_BG_LDS_TILES 0 /* source bounding box of each 256-pixel group staged in LDS by coalesced row reads;
+                             groups whose box does not fit (strong lensing) use the global gather */
+#define LT_BG_GLOBAL 1    /* one global nearest-neighbour read per pixel */
 
 /* Counters produced by the epilogue kernel (one 64-bit word each, device or host). */
 #define LT_STAT_RAYS 0      /* rays integrated */
@@ -96,6 +101,8 @@ typedef struct lt_opts {
 #define LT_STAT_WAVES 7      /* wavefronts of the integrate kernel                                     */
 #define LT_STAT_CLK_CYCLES 8 /* shader-clock cycles (s_memtime) over the lifetime of every 64th wave   */
 #define LT_STAT_CLK_TICKS 9  /* 100 MHz real-time ticks (s_memrealtime) over the same lifetimes        */
+#define LT_STAT_BG_TILES_LDS 10    /* epilogue, lensed background: 256-pixel groups whose source texels were staged in LDS */
+#define LT_STAT_BG_TILES_GLOBAL 11 /* ... and groups that fell back to the per-pixel global gather                  */
 #define LT_STAT_WORDS 16
 
 typedef struct lt_stats {
@@ -178,10 +185,10 @@ int lt_render_dev(const lt_camera *cam, const lt_metric *metric, const lt_opts *
                   uint64_t *d_stats);
 
 /* Same with HOST pointers (stages the background H2D, results D2H, synchronises); stats may be NULL.
- * Device-side buffers persist per (device, stream).  A destination inside a block from lt_host_alloc
- * (or any other pinned / registered host memory) is written by DMA directly; a pageable destination is
- * filled through the library's pinned staging area by host threads while later pieces still cross PCIe
- * (LT_D2H_THREADS, default 6; LT_D2H_PIECE_KB, default 4096). */
+ * Device-side buffers persist per (device, stream).  Every output is copied straight into the caller's memory:
+ * into a block from lt_host_alloc (or other pinned / registered host memory) by DMA at PCIe rate; into pageable
+ * memory through the HIP runtime, which pins the pages on the fly (about 10x slower the first time a buffer is
+ * used, PCIe rate when the same buffer is passed again). */
 int lt_render(const lt_camera *cam, const lt_metric *metric, const lt_opts *opts,
               const float *bg, int32_t bg_channels, float *out_fa, uint16_t *out_w,
               int8_t *out_status, uint32_t *out_steps, float *out_rgb, uint8_t *out_rgba,

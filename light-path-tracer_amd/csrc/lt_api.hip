@@ -16,7 +16,6 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
-#include <thread>
 #include <vector>
 
 #ifndef LT_BUILD_ID
@@ -74,23 +73,21 @@ static int require_device()
 // ---------------------------------------------------------------------------------------------
 // per-device context.  Everything a call needs beyond the caller's own buffers is owned per
 // (device, stream): the grow-only workspace of ray records, and for the host-pointer entry points
-// the device-side outputs and a pinned staging area.  Two calls on different streams of one device
+// the device-side inputs and outputs.  Two calls on different streams of one device
 // therefore never share memory and may run concurrently; calls on the same stream are ordered by
 // the stream.  Nothing is allocated per call once the buffers have grown to the frame size.
 // ---------------------------------------------------------------------------------------------
 struct EventQuad { hipEvent_t e[4]; };
 
-struct Grow { // grow-only allocation (device memory, or pinned host memory when `host` is set)
+struct Grow { // grow-only device allocation
     void *p = nullptr;
     size_t bytes = 0;
-    bool host = false;
 };
 
 struct StreamSlot {
     hipStream_t stream = nullptr;
     Grow ws;     // ray records of lt_render_dev / the batch twins
     Grow dev;    // lt_render / batch twins: device-side inputs and outputs
-    Grow pinned; // lt_render: pinned host staging for destinations that are not pinned themselves
     EventQuad own{}; // lt_render's private timing events (created on first use)
     bool own_ok = false;
 };
@@ -136,20 +133,19 @@ static int grow(Grow &g, size_t need, hipStream_t stream)
     if (need <= g.bytes) return LT_OK;
     if (g.p) {
         HIP_TRY(hipStreamSynchronize(stream));
-        if (g.host) HIP_TRY(hipHostFree(g.p)); else HIP_TRY(hipFree(g.p));
+        HIP_TRY(hipFree(g.p));
         g.p = nullptr;
         g.bytes = 0;
     }
     need = (need + 4095) & ~(size_t)4095;
-    if (g.host) HIP_TRY(hipHostMalloc(&g.p, need, hipHostMallocDefault)); else HIP_TRY(hipMalloc(&g.p, need));
+    HIP_TRY(hipMalloc(&g.p, need));
     g.bytes = need;
     return LT_OK;
 }
 
 static void release(Grow &g)
 {
-    if (!g.p) return;
-    if (g.host) (void)hipHostFree(g.p); else (void)hipFree(g.p);
+    if (g.p) (void)hipFree(g.p);
     g.p = nullptr;
     g.bytes = 0;
 }
@@ -211,7 +207,7 @@ extern "C" int lt_shutdown(void)
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (StreamSlot *sl : c.slots) {
-            release(sl->ws); release(sl->dev); release(sl->pinned);
+            release(sl->ws); release(sl->dev);
             if (sl->own_ok) for (auto &e : sl->own.e) (void)hipEventDestroy(e);
             delete sl;
         }
@@ -233,6 +229,7 @@ extern "C" int lt_shutdown(void)
 extern "C" void lt_default_opts(lt_opts *o)
 {
     memset(o, 0, sizeof(*o));
+    o->bg_sampling = LT_BG_GLOBAL; // measured (profiles/r02_background_sampling.txt): the gather itself is 0.06 ms of a 4096^2 frame
     o->integrator = LT_INTEGRATOR_RK4;
     o->precision = 32;
     o->schedule = LT_SCHED_DIRECT;
@@ -531,6 +528,8 @@ static int check_opts(const lt_metric *metric, lt_opts *o)
         return fail(LT_ERR_INVALID_ARG, "unknown integrator %d", o->integrator);
     if (o->schedule != LT_SCHED_DIRECT && o->schedule != LT_SCHED_QUEUE)
         return fail(LT_ERR_INVALID_ARG, "unknown schedule %d", o->schedule);
+    if (o->bg_sampling != LT_BG_LDS_TILES && o->bg_sampling != LT_BG_GLOBAL)
+        return fail(LT_ERR_INVALID_ARG, "unknown bg_sampling %d", o->bg_sampling);
     if (o->h_max <= 0.0) o->h_max = metric->kind == LT_METRIC_KERR ? 1.0 : 0.05;
     if (o->phi_max <= 0.0) o->phi_max = 50.0;
     if (o->row_block <= 0) o->row_block = 16;
@@ -648,8 +647,17 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
                            : launch_integrate<double>(mc, o, lambda_max, w, n_q, s, d_stats);
     if (rc) return rc;
     if ((rc = tm.mark(2, s))) return rc;
-    if (o.precision == 32) k_epilogue_frame<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
-    else k_epilogue_frame<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+    // background tiles staged in LDS when a background is lensed (opts->bg_sampling)
+    const bool lds_path = o.bg_sampling == LT_BG_LDS_TILES && d_bg && (d_rgb || d_rgba);
+    if (lds_path) {
+        int64_t n16 = (int64_t)((c.W + 15) / 16) * ((c.rows_local + 15) / 16);
+        gp = (unsigned)(n16 < 4096 ? n16 : 4096);
+        if (o.precision == 32) k_epilogue_frame_lds<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
+        else k_epilogue_frame_lds<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+    } else {
+        if (o.precision == 32) k_epilogue_frame<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
+        else k_epilogue_frame<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+    }
     HIP_TRY(hipGetLastError());
     if ((rc = tm.mark(3, s))) return rc;
     tm.finish();
@@ -673,7 +681,7 @@ struct DevBuf {
 
 // ---- pinned host memory for callers of the host-pointer entry points ---------------------------
 // A destination inside such a block is written by DMA straight from the device (PCIe rate); any other
-// destination is pageable memory and goes through the library's pinned staging + host copies.
+// destination is pageable memory, which the HIP runtime has to pin page by page during the copy.
 extern "C" void *lt_host_alloc(size_t bytes)
 {
     if (lt_device_count() <= 0) { (void)fail(LT_ERR_NO_DEVICE, "lt_host_alloc: no HIP device visible"); return nullptr; }
@@ -690,73 +698,17 @@ extern "C" int lt_host_free(void *p)
     return LT_OK;
 }
 
-static bool is_pinned_host(const void *p)
-{
-    hipPointerAttribute_t a;
-    memset(&a, 0, sizeof(a));
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
-
-// Device -> host for a list of outputs.  Pinned destinations: one async DMA each.  Pageable destinations: the
-// bytes are cut into pieces that are DMA'd into the slot's pinned staging area back to back, each piece followed
-// by an event; host threads copy piece i to its destination as soon as its event has fired, i.e. while the
-// later pieces are still crossing PCIe.
+// Device -> host for a list of outputs: one asynchronous copy each, straight into the caller's memory.  Into
+// pinned memory (lt_host_alloc) that is a DMA at PCIe rate (measured 55 GB/s: 1.2 ms for a 4096^2 RGBA8 frame).
+// Into pageable memory the HIP runtime pins the destination pages on the fly: 14 ms for the same 64 MiB the first
+// time a buffer is used, 1.2 ms when the same buffer is passed again (tools/scratch/hostmem_probe.cpp).  A staging
+// scheme of our own (pinned bounce buffer + host copy threads) was built and measured slower than that.
 struct OutCopy { void *dst; const void *src; size_t bytes; };
 
-static int copy_out(StreamSlot *sl, hipStream_t s, const std::vector<OutCopy> &outs)
+static int copy_out(hipStream_t s, const std::vector<OutCopy> &outs)
 {
-    struct Piece { char *dst; const char *stage; size_t bytes; hipEvent_t ev; };
-    static const size_t piece_bytes = (size_t)env_int("LT_D2H_PIECE_KB", 4096) * 1024;
-    size_t staged = 0;
     for (const OutCopy &o : outs)
-        if (o.bytes && !is_pinned_host(o.dst)) staged += (o.bytes + 255) & ~(size_t)255;
-    int rc;
-    if ((rc = grow(sl->pinned, staged, s))) return rc;
-    std::vector<Piece> pieces;
-    size_t off = 0;
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    for (const OutCopy &o : outs) {
-        if (!o.bytes) continue;
-        if (is_pinned_host(o.dst)) {
-            HIP_TRY(hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToHost, s));
-            continue;
-        }
-        char *stage = (char *)sl->pinned.p + off;
-        off += (o.bytes + 255) & ~(size_t)255;
-        for (size_t b = 0; b < o.bytes; b += piece_bytes) {
-            size_t len = o.bytes - b < piece_bytes ? o.bytes - b : piece_bytes;
-            Piece pc{(char *)o.dst + b, stage + b, len, nullptr};
-            HIP_TRY(hipMemcpyAsync((void *)pc.stage, (const char *)o.src + b, len, hipMemcpyDeviceToHost, s));
-            hipError_t e = hipEventCreateWithFlags(&pc.ev, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(pc.ev, s);
-            if (e != hipSuccess) {
-                for (Piece &q : pieces) (void)hipEventDestroy(q.ev);
-                return fail(LT_ERR_HIP, "event for a device-to-host piece: %s", hipGetErrorString(e));
-            }
-            pieces.push_back(pc);
-        }
-    }
-    if (!pieces.empty()) {
-        static const int max_threads = env_int("LT_D2H_THREADS", 6);
-        int nt = (int)pieces.size() < max_threads ? (int)pieces.size() : max_threads;
-        if (nt < 1) nt = 1;
-        std::vector<int> errs((size_t)nt, 0);
-        auto work = [&](int t) {
-            (void)hipSetDevice(dev);
-            for (size_t i = (size_t)t; i < pieces.size(); i += (size_t)nt) {
-                if (hipEventSynchronize(pieces[i].ev) != hipSuccess) { errs[(size_t)t] = 1; continue; }
-                memcpy(pieces[i].dst, pieces[i].stage, pieces[i].bytes);
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
-        work(0);
-        for (auto &t : th) t.join();
-        for (Piece &q : pieces) (void)hipEventDestroy(q.ev);
-        for (int e : errs) if (e) return fail(LT_ERR_HIP, "waiting for a device-to-host piece failed");
-    }
+        if (o.bytes) HIP_TRY(hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToHost, s));
     return LT_OK;
 }
 
@@ -811,7 +763,7 @@ extern "C" int lt_render(const lt_camera *cam, const lt_metric *metric, const lt
     if (out_status) outs.push_back({out_status, base + o_st, n});
     if (out_steps) outs.push_back({out_steps, base + o_steps, n * 4});
     if (out_rgb) outs.push_back({out_rgb, base + o_rgb, n * nch * 4});
-    if ((rc = copy_out(sl, s, outs))) return rc;
+    if ((rc = copy_out(s, outs))) return rc;
     HIP_TRY(hipMemcpyAsync(st.counters, base + o_stats, LT_STAT_WORDS * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (rows > 0) {
@@ -919,7 +871,7 @@ extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, co
         rows_of(out_status, P.o_st, 1);
         rows_of(out_steps, P.o_steps, 4);
         rows_of(out_rgb, P.o_rgb, (size_t)nch * 4);
-        if ((rc = copy_out(P.sl, P.s, outs))) return rc;
+        if ((rc = copy_out(P.s, outs))) return rc;
         memset(&each[(size_t)p], 0, sizeof(lt_stats));
         HIP_TRY(hipMemcpyAsync(each[(size_t)p].counters, P.base + P.o_stats, LT_STAT_WORDS * 8, hipMemcpyDeviceToHost, P.s));
     }

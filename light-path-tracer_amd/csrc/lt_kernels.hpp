@@ -619,21 +619,24 @@ struct FrameOut {
 };
 
 // Colour of one pixel, render_lensed_image (image_lens.py:296-397); rgb[3] float32.
-__device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int ix, int grow, float fa32,
-                                      int winding, float *rgb, int &nch)
+// shade_source decides everything except the texel read: returns true if the pixel shows the background texel
+// (sx, sy), false if its colour is already in rgb (black, winding colour, white in shadow mode, magenta).
+__device__ __forceinline__ bool shade_source(const CamConsts &c, const FrameOut &o, int ix, int grow, float fa32,
+                                             int winding, float *rgb, int &nch, int &sx_out, int &sy_out)
 {
     nch = o.bg ? o.bg_c : 3;
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
-    if (!isfinite(fa32)) return;
+    sx_out = sy_out = 0;
+    if (!isfinite(fa32)) return false;
     const float half_pi_f = 1.57079637050628662109375f; // float32(pi/2): NEP-50 weak-scalar compare
     if (fa32 > half_pi_f) {
         const float wc[5][3] = {{0.0f, 0.2f, 1.0f}, {0.0f, 0.7f, 1.0f}, {0.0f, 1.0f, 0.4f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.4f, 0.0f}};
         int idx = winding > 4 ? 4 : winding;
         if (nch == 1) rgb[0] = wc[idx][0] * 0.299f + wc[idx][1] * 0.587f + wc[idx][2] * 0.114f;
         else { rgb[0] = wc[idx][0]; rgb[1] = wc[idx][1]; rgb[2] = wc[idx][2]; }
-        return;
+        return false;
     }
-    if (!o.bg) { rgb[0] = rgb[1] = rgb[2] = 1.0f; return; } // shadow mode: escaped = white
+    if (!o.bg) { rgb[0] = rgb[1] = rgb[2] = 1.0f; return false; } // shadow mode: escaped = white
     double x_cam = ((double)ix - c.half_W) / c.fx;
     double y_cam = ((double)grow - c.half_H) / c.fy;
     double denom = sqrt(1.0 + x_cam * x_cam + y_cam * y_cam);
@@ -659,12 +662,27 @@ __device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int
         sy = (long long)rint(svy / svz * c.fy + c.half_H);
     }
     if (front && sy >= 0 && sy < c.H && sx >= 0 && sx < c.W) {
+        sx_out = (int)sx; sy_out = (int)sy;
+        return true;
+    }
+    // magenta, image_lens.py:381-388
+    rgb[0] = 1.0f;
+    if (nch == 3) { rgb[1] = 0.0f; rgb[2] = 1.0f; }
+    return false;
+}
+
+__device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int ix, int grow, float fa32,
+                                      int winding, float *rgb, int &nch)
+{
+    int sx, sy;
+    if (shade_source(c, o, ix, grow, fa32, winding, rgb, nch, sx, sy)) {
+#ifdef LT_DEBUG_NOFETCH // diagnostic build only: everything but the texel read (prices the gather itself)
+        rgb[0] = (float)sx * 1e-9f; rgb[1] = (float)sy * 1e-9f; rgb[2] = 0.0f;
+#else
         const float *p = o.bg + ((size_t)sy * c.W + sx) * nch;
         rgb[0] = p[0];
         if (nch == 3) { rgb[1] = p[1]; rgb[2] = p[2]; }
-    } else { // magenta, image_lens.py:381-388
-        rgb[0] = 1.0f;
-        if (nch == 3) { rgb[1] = 0.0f; rgb[2] = 1.0f; }
+#endif
     }
 }
 
@@ -704,6 +722,108 @@ __global__ void __launch_bounds__(256, 3) k_epilogue_frame(CamConsts c, MetricCo
                 reinterpret_cast<uchar4 *>(o.rgba)[p] = px;
             }
         }
+    }
+    flush_stats(o.stats, acc);
+}
+
+// ---- K3 with the background tile staged in LDS (north-star: "LDS staging of the background-image tile") ----
+// One block iteration covers a 16x16 tile of output pixels.  The lens map displaces a pixel by hundreds of source
+// pixels even far from the hole (4M/b rad at r_obs = 100 M is ~700 px at 4096^2), but smoothly: a 16x16 output
+// tile shows a compact patch of the source image -- about 16x16 texels, fewer where the map demagnifies -- while a
+// 256-pixel ROW segment shows a thin diagonal whose bounding box is ~100 rows high (measured: 98 % of row groups did
+// not fit 24 KiB).  So the tile is 2-D.  The block finds the bounding box of the texels its pixels show (wave
+// min/max + four LDS atomics per wave), loads that box with coalesced row reads -- every source byte once,
+// whatever the magnification -- and the 256 pixels then pick their texels out of LDS.  Where the map stretches or
+// folds (the Einstein ring, the critical curve, row blocks of a partition that are not 16 rows high) the box does
+// not fit BG_LDS_FLOATS and the block falls back to the per-pixel global gather of k_epilogue_frame.  Same texels
+// either way: results are bit-identical.
+constexpr int BG_LDS_FLOATS = 6144; // 24 KiB per block: 3 blocks per CU use 72 of the 160 KiB
+
+template <typename T>
+__global__ void __launch_bounds__(256, 3) k_epilogue_frame_lds(CamConsts c, MetricConsts m,
+                                                            const typename Vec4<T>::type *__restrict__ fin0,
+                                                            const typename Vec4<T>::type *__restrict__ fin1, FrameOut o)
+{
+    __shared__ float tile[BG_LDS_FLOATS];
+    __shared__ int bb[4]; // x0, x1, y0, y1 of the texels this iteration's pixels show
+    const int tiles_x = (c.W + 15) >> 4, tiles_y = (c.rows_local + 15) >> 4;
+    const int n_tiles = tiles_x * tiles_y;
+    const int nch = o.bg_c;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    StatAcc acc;
+    unsigned long long staged = 0, fallback = 0; // tiles served from LDS / by the global gather (thread 0)
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int tY = t / tiles_x, tX = t - tY * tiles_x;
+        const int ix = tX * 16 + lx, lrow = tY * 16 + ly;
+        const bool active = ix < c.W && lrow < c.rows_local;
+        const int64_t p = (int64_t)lrow * c.W + ix;
+        float rgb[3] = {0.0f, 0.0f, 0.0f};
+        int sx = 0, sy = 0, pn = nch;
+        bool tex = false;
+        if (active) {
+            int src_row = lrow;
+            if (c.use_tb && lrow >= c.H - c.H / 2) src_row = c.H - 1 - lrow; // quirk Q1 (image_lens.py:272-276)
+            RayResult res;
+            load_result<T>(m, fin0, fin1, pixel_to_q(c, ix, src_row), res);
+            if (src_row == lrow) acc.add(res);
+            float fa32 = (res.status == 1) ? (float)res.fa : __builtin_nanf("");
+            long long wl = res.n_half < 0 ? 0 : (res.n_half > 65535 ? 65535 : res.n_half);
+            if (o.fa) o.fa[p] = fa32;
+            if (o.w) o.w[p] = (uint16_t)wl;
+            if (o.status) o.status[p] = (int8_t)res.status;
+            if (o.steps) o.steps[p] = res.steps;
+            tex = shade_source(c, o, ix, local_to_global_row(c, lrow), fa32, (int)wl, rgb, pn, sx, sy);
+        }
+        if (threadIdx.x == 0) { bb[0] = 0x7fffffff; bb[1] = -1; bb[2] = 0x7fffffff; bb[3] = -1; }
+        __syncthreads();
+        int x0 = tex ? sx : 0x7fffffff, x1 = tex ? sx : -1, y0 = tex ? sy : 0x7fffffff, y1 = tex ? sy : -1;
+        for (int off = 32; off > 0; off >>= 1) {
+            int a = __shfl_xor(x0, off, 64), b = __shfl_xor(x1, off, 64), d = __shfl_xor(y0, off, 64), e = __shfl_xor(y1, off, 64);
+            x0 = a < x0 ? a : x0; x1 = b > x1 ? b : x1; y0 = d < y0 ? d : y0; y1 = e > y1 ? e : y1;
+        }
+        if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+            atomicMin(&bb[0], x0); atomicMax(&bb[1], x1); atomicMin(&bb[2], y0); atomicMax(&bb[3], y1);
+        }
+        __syncthreads();
+        const int bx0 = bb[0], bx1 = bb[1], by0 = bb[2], by1 = bb[3];
+        const int w = bx1 - bx0 + 1, h = by1 - by0 + 1;
+        const bool any = bx1 >= 0;                                                  // block-uniform
+        const bool fits = any && (int64_t)w * h * nch <= (int64_t)BG_LDS_FLOATS;    // block-uniform
+        if (fits) {
+            const int rowf = w * nch;
+            // wave v loads box rows v, v + 4, ...: each a contiguous run of rowf floats of the source image
+            for (int r = threadIdx.x >> 6; r < h; r += 4) {
+                const float *src = o.bg + ((size_t)(by0 + r) * c.W + bx0) * nch;
+                for (int col = threadIdx.x & 63; col < rowf; col += 64) tile[r * rowf + col] = src[col];
+            }
+            __syncthreads();
+            if (tex) {
+                const float *tp = tile + ((sy - by0) * w + (sx - bx0)) * nch;
+                rgb[0] = tp[0];
+                if (nch == 3) { rgb[1] = tp[1]; rgb[2] = tp[2]; }
+            }
+        } else if (tex) {
+            const float *tp = o.bg + ((size_t)sy * c.W + sx) * nch;
+            rgb[0] = tp[0];
+            if (nch == 3) { rgb[1] = tp[1]; rgb[2] = tp[2]; }
+        }
+        if (threadIdx.x == 0 && any) { if (fits) ++staged; else ++fallback; }
+        if (active) {
+            if (o.rgb) for (int ch = 0; ch < pn; ++ch) o.rgb[p * pn + ch] = rgb[ch];
+            if (o.rgba) { // matplotlib imsave: (x * 255).astype(uint8) in float32, alpha 255
+                uchar4 px;
+                px.x = (uint8_t)(rgb[0] * 255.0f);
+                px.y = (uint8_t)(rgb[pn == 1 ? 0 : 1] * 255.0f);
+                px.z = (uint8_t)(rgb[pn == 1 ? 0 : 2] * 255.0f);
+                px.w = 255;
+                reinterpret_cast<uchar4 *>(o.rgba)[p] = px;
+            }
+        }
+        __syncthreads(); // bb and tile are rewritten by the next iteration
+    }
+    if (o.stats && threadIdx.x == 0 && (staged | fallback)) {
+        atomicAdd((unsigned long long *)&o.stats[10], staged);
+        atomicAdd((unsigned long long *)&o.stats[11], fallback);
     }
     flush_stats(o.stats, acc);
 }

@@ -19,6 +19,7 @@ INTEGRATOR_DP45, INTEGRATOR_RK4 = 0, 1
 SCHED_DIRECT, SCHED_QUEUE = 0, 1
 STAT_RAYS, STAT_STEPS, STAT_RHS_EVALS, STAT_ESCAPED, STAT_CAPTURED, STAT_INVALID = range(6)
 STAT_WAVE_ITERS, STAT_WAVES, STAT_CLK_CYCLES, STAT_CLK_TICKS = 6, 7, 8, 9
+STAT_BG_TILES_LDS, STAT_BG_TILES_GLOBAL = 10, 11
 STAT_WORDS = 16
 
 INTEGRATORS = {"dp45": INTEGRATOR_DP45, "rk4": INTEGRATOR_RK4}
@@ -47,7 +48,10 @@ class Opts(C.Structure):
                 ("tb_symmetry", C.c_int32), ("loop_around", C.c_int32), ("row_block", C.c_int32),
                 ("n_parts", C.c_int32), ("part", C.c_int32),
                 ("axis_refine_frac", C.c_double), ("phi_max", C.c_double), ("h_max", C.c_double),
-                ("stream", C.c_void_p), ("timing", C.c_int32), ("reserved", C.c_int32)]
+                ("stream", C.c_void_p), ("timing", C.c_int32), ("bg_sampling", C.c_int32)]
+
+
+BG_LDS_TILES, BG_GLOBAL = 0, 1
 
 
 class DenseOpts(C.Structure):
@@ -415,7 +419,8 @@ def stats_dict(counters, prologue_ms=0.0, integrate_ms=0.0, epilogue_ms=0.0):
     clk = c[STAT_CLK_CYCLES] / c[STAT_CLK_TICKS] * 100.0 if c[STAT_CLK_TICKS] else 0.0   # ticks are 100 MHz
     return dict(rays=c[STAT_RAYS], steps=c[STAT_STEPS], rhs_evals=c[STAT_RHS_EVALS], escaped=c[STAT_ESCAPED],
                 captured=c[STAT_CAPTURED], invalid=c[STAT_INVALID], wave_iters=c[STAT_WAVE_ITERS],
-                waves=c[STAT_WAVES], clock_mhz=clk,
+                waves=c[STAT_WAVES], clock_mhz=clk, bg_tiles_lds=c[STAT_BG_TILES_LDS],
+                bg_tiles_global=c[STAT_BG_TILES_GLOBAL],
                 prologue_ms=prologue_ms, integrate_ms=integrate_ms, epilogue_ms=epilogue_ms)
 
 

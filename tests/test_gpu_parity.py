@@ -634,41 +634,34 @@ def test_two_streams_do_not_share_a_workspace():
     """Concurrency contract of ltrace.h: lt_render_dev calls on DIFFERENT streams of one device own separate ray
     records (per (device, stream) workspaces), so two frames in flight at once come out as when rendered alone.
     (Round 1 shared one workspace per device: a second stream overwrote the first frame's records.)"""
-    import torch
-    dev = torch.device("cuda", 0)
+    import hipmini
     cams = [_cam(512, 384, 50.0), _cam(448, 512, 50.0, psi=(0.03, 0.1))]
     met = ltrace.Metric(1, 0, 1.0, 0.9)
-    alone = []
-    for cam in cams:
-        r = ltrace.render(cam, met, ltrace.default_opts(precision=32), want=("fa", "status", "steps"))
-        alone.append(r)
-    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    bufs = []
+    alone = [ltrace.render(cam, met, ltrace.default_opts(precision=32), want=("fa", "status", "steps")) for cam in cams]
+    streams = [hipmini.Stream(), hipmini.Stream()]
+    bufs = [(hipmini.DeviceArray((cam.height, cam.width), np.float32), hipmini.DeviceArray((cam.height, cam.width), np.int8),
+             hipmini.DeviceArray((cam.height, cam.width), np.uint32)) for cam in cams]
     for rep in range(3):                       # interleave launches: both frames are in flight together
-        bufs = []
-        for cam, s in zip(cams, streams):
-            fa = torch.empty((cam.height, cam.width), dtype=torch.float32, device=dev)
-            stt = torch.empty((cam.height, cam.width), dtype=torch.int8, device=dev)
-            stp = torch.empty((cam.height, cam.width), dtype=torch.int32, device=dev)
+        for cam, s, (fa, stt, stp) in zip(cams, streams, bufs):
             o = ltrace.default_opts(precision=32)
-            o.stream = s.cuda_stream
-            ltrace.render_dev(cam, met, o, d_fa=fa.data_ptr(), d_status=stt.data_ptr(), d_steps=stp.data_ptr())
-            bufs.append((fa, stt, stp))
-    torch.cuda.synchronize(dev)
+            o.stream = s.ptr
+            ltrace.render_dev(cam, met, o, d_fa=fa.ptr, d_status=stt.ptr, d_steps=stp.ptr)
+    for s in streams:
+        s.synchronize()
     for (fa, stt, stp), ref in zip(bufs, alone):
-        assert np.array_equal(fa.cpu().numpy(), ref["fa"], equal_nan=True)
-        assert np.array_equal(stt.cpu().numpy(), ref["status"])
-        assert np.array_equal(stp.cpu().numpy().astype(np.uint32), ref["steps"])
+        assert np.array_equal(fa.get(), ref["fa"], equal_nan=True)
+        assert np.array_equal(stt.get(), ref["status"])
+        assert np.array_equal(stp.get(), ref["steps"])
     # a batch trace on the default stream while a frame is in flight on a side stream
     o = ltrace.default_opts(precision=32)
-    o.stream = streams[0].cuda_stream
+    o.stream = streams[0].ptr
     fa, stt, stp = bufs[0]
-    ltrace.render_dev(cams[0], met, o, d_fa=fa.data_ptr(), d_status=stt.data_ptr(), d_steps=stp.data_ptr())
+    ltrace.render_dev(cams[0], met, o, d_fa=fa.ptr, d_status=stt.ptr, d_steps=stp.ptr)
     al = np.linspace(0.05, 0.3, 3000)
     bf, bw = np.full(al.size, np.nan), np.zeros(al.size, dtype=np.int64)
     ltrace.trace_batch_kerr(1.0, 0.9, 50.0, al, np.full(al.size, 0.7), np.pi / 2, 5000.0, None, bf, bw, precision=32)
-    torch.cuda.synchronize(dev)
-    assert np.array_equal(fa.cpu().numpy(), alone[0]["fa"], equal_nan=True)
+    streams[0].synchronize()
+    assert np.array_equal(fa.get(), alone[0]["fa"], equal_nan=True)
     bf2, bw2 = np.full(al.size, np.nan), np.zeros(al.size, dtype=np.int64)
     ltrace.trace_batch_kerr(1.0, 0.9, 50.0, al, np.full(al.size, 0.7), np.pi / 2, 5000.0, None, bf2, bw2, precision=32)
     assert np.array_equal(bf, bf2, equal_nan=True) and np.array_equal(bw, bw2)
@@ -705,3 +698,29 @@ def test_render_multi_and_host_destinations():
     for k in pg:
         assert np.array_equal(pg[k], whole[k], equal_nan=True), k
     assert list(st.counters)[:6] == [whole["stats"][k] for k in ("rays", "steps", "rhs_evals", "escaped", "captured", "invalid")]
+
+
+def test_background_sampling_paths_are_bit_identical():
+    """The LDS-tiled background path (source bounding box of each 256-pixel group staged in LDS) and the per-pixel
+    global gather read the same texels: identical images, RGB / grayscale / wrap-around, off-axis hole, ragged width;
+    and both kinds of group occur (far field: staged; around the ring: fallback)."""
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    for (W, H, psi, gray, la) in ((640, 400, (0.0, 0.0), False, 0), (333, 217, (0.05, -0.1), True, 0), (512, 256, (0.1, 0.3), False, 1)):
+        cam = _cam(W, H, 50.0, psi=psi)
+        bg = _background(H, W, 13)
+        if gray:
+            bg = bg[..., 0].copy()
+        res = {}
+        for mode in (ltrace.BG_LDS_TILES, ltrace.BG_GLOBAL):
+            res[mode] = ltrace.render(cam, met, ltrace.default_opts(precision=32, loop_around=la, bg_sampling=mode), background=bg,
+                                      want=("fa", "winding", "rgb", "rgba"))
+        a, b = res[ltrace.BG_LDS_TILES], res[ltrace.BG_GLOBAL]
+        assert np.array_equal(a["rgb"], b["rgb"]) and np.array_equal(a["rgba"], b["rgba"])
+        assert np.array_equal(a["rgb"], oracle.render(bg, a["fa"], a["winding"], cam.hfov, cam.vfov, psi=psi, loop_around=bool(la)))
+        assert b["stats"]["bg_tiles_lds"] == 0 and b["stats"]["bg_tiles_global"] == 0
+        assert a["stats"]["bg_tiles_lds"] > 0
+        n_tiles = -(-W // 16) * -(-H // 16)
+        assert a["stats"]["bg_tiles_lds"] + a["stats"]["bg_tiles_global"] <= n_tiles
+        assert a["stats"]["bg_tiles_lds"] > 0.5 * n_tiles            # most 16x16 tiles show a compact source patch
+    with pytest.raises(ltrace.LtraceError):
+        ltrace.render(cam, met, ltrace.default_opts(bg_sampling=7), want=("status",))
