@@ -68,13 +68,24 @@ def parse(argv=None):
     ap.add_argument("--metric", choices=["kerr", "schwarzschild"], default="kerr")
     ap.add_argument("--schedule", choices=["direct", "queue"], default=os.environ.get("LT_SCHEDULE", "direct"))
     ap.add_argument("--precision", type=int, default=32)
-    ap.add_argument("--integrator", choices=["rk4", "dp45"], default="rk4")
+    ap.add_argument("--integrator", choices=["rk4", "dp45", "dp45_exact"], default="rk4")
     ap.add_argument("--row-block", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (end-to-end host-pointer frame, longest-ray chain)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg")
     ap.add_argument("--background", action="store_true", help="image_lens workload: lens a synthetic background")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="1: frames strictly one after the other on one stream (the contract's per-launch roofline). "
+                         "F > 1: frame i runs on stream i %% F with its own buffers, so the tail of one frame (a few "
+                         "lone wavefronts finishing the longest rays) overlaps the bulk of the next: throughput mode")
+    ap.add_argument("--emulate-parts", type=int, default=0,
+                    help="one GPU plays rank --emulate-part of an N-GPU run: renders only that row partition (no gather); "
+                         "tools/part_bench.py uses it to project the N-GPU frame time from one GPU")
+    ap.add_argument("--emulate-part", type=int, default=0)
+    ap.add_argument("--pipelined-extra", type=int, default=3,
+                    help="after the timed region, time the same K frames again with this many frames in flight and report it "
+                         "as `pipelined` (0 / 1: skip)")
     ap.add_argument("--bg-sampling", choices=["lds", "global"], default="lds", help="epilogue background path (LT_BG_*)")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; tests use gloo)")
     ap.add_argument("--stub-render", action="store_true",
@@ -149,7 +160,7 @@ def cpu_baseline(args, fov):
     os.environ["OMP_NUM_THREADS"] = str(cores)             # before libgomp is first initialised in this process
     from oracle import oracle
     kind = args.metric
-    kw = dict(integrator=args.integrator, perf_build=True)
+    kw = dict(integrator="rk4" if args.integrator == "rk4" else "dp45", perf_build=True)
     oracle.lookup(kind, 1.0, args.a, args.r_obs, 64, 64, fov, fov, **kw)       # compiles; spins the threads up
     t0 = time.perf_counter()
     oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, **kw)
@@ -316,37 +327,51 @@ def main(argv=None):
     met = ltrace.Metric(ltrace.METRIC_KERR if args.metric == "kerr" else ltrace.METRIC_SCHWARZSCHILD, 0, 1.0,
                         args.a if args.metric == "kerr" else 0.0)
     rb = args.row_block
-    rows_max = max(ltrace.local_rows(size, rb, world, p) for p in range(world))
+    n_parts, part = (args.emulate_parts, args.emulate_part) if (args.emulate_parts and world == 1) else (world, rank)
+    rows_max = max(ltrace.local_rows(size, rb, n_parts, p) for p in range(n_parts))
 
-    # device buffers (torch owns the memory; the library only sees raw pointers)
-    fg = sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank)   # RGBA8 framebuffer
-    d_rgba = fg.local
-    d_fa = torch.empty((rows_max, size), dtype=torch.float32, device=dev)
-    d_w = torch.empty((rows_max, size), dtype=torch.int16, device=dev)
+    # device buffers (torch owns the memory; the library only sees raw pointers); one set per frame in flight
+    F = max(1, args.frames_in_flight)
     d_stats = torch.zeros(ltrace.STAT_WORDS, dtype=torch.int64, device=dev)
     d_bg = None
     if args.background:
         g = torch.Generator(device="cpu").manual_seed(0)
         d_bg = (torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8).to(torch.float32) / 255.0).to(dev)
+    torch.cuda.synchronize(dev)
+    def make_sets(nf):
+        out = []
+        for f in range(nf):
+            st = torch.cuda.current_stream(dev) if nf == 1 else torch.cuda.Stream(dev)
+            o = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
+                                    row_block=rb, n_parts=n_parts, part=part, timing=1,
+                                    bg_sampling=ltrace.BG_LDS_TILES if args.bg_sampling == "lds" else ltrace.BG_GLOBAL)
+            o.stream = st.cuda_stream
+            fg = (sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank) if n_parts == world else
+                  sharding.FrameGather(rows_max, size, 4, torch.uint8, dev, rows_max, 1, 0))          # emulated rank: no gather
+            out.append(dict(stream=st, opts=o, fg=fg,   # RGBA8 framebuffer
+                            fa=torch.empty((rows_max, size), dtype=torch.float32, device=dev),
+                            w=torch.empty((rows_max, size), dtype=torch.int16, device=dev)))
+        return out
 
-    stream = torch.cuda.current_stream(dev)
-    opts = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
-                               row_block=rb, n_parts=world, part=rank, timing=1,
-                               bg_sampling=ltrace.BG_LDS_TILES if args.bg_sampling == "lds" else ltrace.BG_GLOBAL)
-    opts.stream = stream.cuda_stream
+    sets = make_sets(F)
+    stream = sets[0]["stream"]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(args.steps, 1))]   # frame start / rendered / gathered
 
-    def step(i=None):
-        if i is not None:
-            ev[3 * i].record(stream)
-        ltrace.render_dev(cam, met, opts, d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
-                          d_fa=d_fa.data_ptr(), d_w=d_w.data_ptr(), d_rgba=d_rgba.data_ptr(),
-                          d_stats=d_stats.data_ptr())
-        if i is not None:
-            ev[3 * i + 1].record(stream)
-        full = fg.gather(stream.cuda_stream)   # N > 1: RCCL gather to rank 0 + row un-permute there
-        if i is not None:
-            ev[3 * i + 2].record(stream)
+    def step(i=None, k=0, sets_=None):
+        ss = sets_ or sets
+        b = ss[k % len(ss)]
+        st = b["stream"]
+        with torch.cuda.stream(st):
+            if i is not None:
+                ev[3 * i].record(st)
+            ltrace.render_dev(cam, met, b["opts"], d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
+                              d_fa=b["fa"].data_ptr(), d_w=b["w"].data_ptr(), d_rgba=b["fg"].local.data_ptr(),
+                              d_stats=d_stats.data_ptr())
+            if i is not None:
+                ev[3 * i + 1].record(st)
+            full = b["fg"].gather(st.cuda_stream)   # N > 1: RCCL gather to rank 0 + row un-permute there
+            if i is not None:
+                ev[3 * i + 2].record(st)
         return full
 
     def fence():
@@ -354,15 +379,15 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    for j in range(args.warmup):
+        step(None, j)
     fence()
     ltrace.timing_collect()            # drop warm-up events
     d_stats.zero_()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, i)
     fence()
     elapsed = time.perf_counter() - t0
     tm = ltrace.timing_collect()
@@ -400,9 +425,32 @@ def main(argv=None):
     ms_per_step = elapsed / steps * 1e3
     value = rays_per_frame / (elapsed / steps) / 1e6
 
+    # second region, same K and W, frames pipelined 3 deep (every rank takes part: the gather is collective)
+    pipelined = None
+    if F == 1 and not args.no_extras and args.pipelined_extra > 1:
+        psets = make_sets(args.pipelined_extra)
+        for j in range(max(args.warmup, args.pipelined_extra)):
+            step(None, j, psets)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(None, i, psets)
+        fence()
+        tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        ltrace.timing_collect()
+        pel = float(tp.item())
+        pipelined = {"frames_in_flight": args.pipelined_extra, "value": round(rays_per_frame / (pel / steps) / 1e6, 2), "unit": "Mrays/s",
+                     "ms_per_step": round(pel / steps * 1e3, 4),
+                     "what": f"the same {args.steps} frames after the same warm-up, frame i on stream i % {args.pipelined_extra} with its own buffers: "
+                             "the tail of a frame (a few lone wavefronts finishing its longest rays) overlaps the bulk of the next. "
+                             "Throughput of a frame SEQUENCE; `value` above is frames strictly one after the other"}
+        del psets
+
     # untimed extras (rank 0, one GPU): longest-ray chain and the host-pointer end-to-end frame
     chain = e2e = None
-    if rank == 0 and world == 1 and not args.no_extras and args.metric == "kerr":
+    if rank == 0 and world == 1 and n_parts == 1 and not args.no_extras and args.metric == "kerr":
         d_steps = torch.empty((size, size), dtype=torch.int32, device=dev)
         o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
         o1.stream = stream.cuda_stream
@@ -419,7 +467,9 @@ def main(argv=None):
         if args.background:
             workload += "_lensed_background"
         kernel = (f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct")
-        key = f"{workload}|f{args.precision}|{args.schedule}|parts{world}"
+        key = f"{workload}|f{args.precision}|{args.schedule}|parts{n_parts}"
+        if n_parts != world:
+            key += f"|part{part}"
         bid = ltrace.build_id()
         # --- executed work of the priced launch (the slowest rank's integrate kernel)
         k_iters, k_waves, k_cyc, k_ticks, k_steps, k_rays = all_k[slow]
@@ -446,6 +496,13 @@ def main(argv=None):
             lane_flops = 64 * 2                                   # one FMA per lane per issue slot
             roof["achieved"] = round(slots_per_s * lane_flops / 1e12, 2)   # FMA-equivalent: every issue slot priced as one FMA
             roof["frac"] = round(slots_per_s / peak_slots, 4)
+            # the same over the whole timed region (prologue, epilogue, gaps and -- with frames in flight -- overlap
+            # included): wave-instructions the integrate kernels of this rank issued / (wall time x issue peak)
+            roof["region_issue_frac"] = round(valu * steps / elapsed / peak_slots, 4)
+            if F > 1:
+                roof["note"] = (f"{F} frames in flight: launches of consecutive frames overlap, so avg_launch_ms (HIP events around "
+                                "each launch) includes time shared with the neighbouring frame and `frac` understates; "
+                                "`region_issue_frac` is the chip-level figure for this mode")
             roof["executed"] = {"valu_wave_insts_per_launch": int(valu), "wave_iters_per_launch": int(iters_per_launch),
                                 "valu_per_wave_iter": round(valu_per_iter, 2), "waves": int(k_waves / steps),
                                 "issue_cycles_per_inst": cyc, "source": valu_src,
@@ -457,7 +514,7 @@ def main(argv=None):
         # --- the reference's as-written count, for the record
         slow_steps, slow_rays = k_steps / steps, k_rays / steps
         if args.metric == "kerr":
-            flops = (slow_steps * F_DP45_ATTEMPT + slow_rays * (F_KERR_FIXED + 188)) if args.integrator == "dp45" else \
+            flops = (slow_steps * F_DP45_ATTEMPT + slow_rays * (F_KERR_FIXED + 188)) if args.integrator != "rk4" else \
                     (slow_steps * F_RK4_STEP + slow_rays * F_KERR_FIXED)
         else:
             flops = slow_steps * F_SCHW_STEP + slow_rays * F_SCHW_FIXED
@@ -480,7 +537,9 @@ def main(argv=None):
             "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "rays_per_frame": rays_per_frame, "schedule": args.schedule, "build_id": bid, "profile_key": key,
-                       "row_partition": f"block-cyclic {rb} rows x {world}", "gather": "rccl" if world > 1 else "none",
+                       "row_partition": f"block-cyclic {rb} rows x {n_parts}" + (f" (emulated rank {part} on one GPU)" if n_parts != world else ""),
+                       "gather": "rccl" if world > 1 else "none",
+                       "frames_in_flight": F,
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
                        "invalid": c[ltrace.STAT_INVALID] // steps,
@@ -492,6 +551,8 @@ def main(argv=None):
                       "render_ms": [round(r[3], 3) for r in per_rank],
                       "gather_ms": [round(r[4], 3) for r in per_rank]},
         }
+        if pipelined:
+            out["pipelined"] = pipelined
         if chain:
             out["chain_floor"] = chain
         if e2e:

@@ -38,6 +38,9 @@ extern "C" {
  * Schwarzschild always uses its orbit-equation RK4, metrics.py:49-117. */
 #define LT_INTEGRATOR_DP45 0
 #define LT_INTEGRATOR_RK4 1
+#define LT_INTEGRATOR_DP45_EXACT 2 /* DP45 with the step-size controller evaluated in float64 exactly as metrics.py:506-522,
+                                      :560-564 writes it (LT_INTEGRATOR_DP45 evaluates it in float32, free of divisions and
+                                      pow): the reference's accept / reject sequence, at a measured cost */
 
 /* ray -> lane scheduling of the integrate kernel */
 #define LT_SCHED_DIRECT 0 /* one work-item per ray, one 8x8 pixel tile per wavefront        */

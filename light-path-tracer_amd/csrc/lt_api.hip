@@ -477,7 +477,8 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
         k_schw_rk4_direct<T><<<grid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q);
     } else {
         KerrConsts<T> k = make_kerr<T>(mc, lambda_max, o.h_max);
-        const bool dp45 = o.integrator == LT_INTEGRATOR_DP45;
+        const bool exact = o.integrator == LT_INTEGRATOR_DP45_EXACT;
+        const bool dp45 = o.integrator == LT_INTEGRATOR_DP45 || exact;
         if (dp45 && sizeof(T) != 8) return fail(LT_ERR_UNSUPPORTED, "DP45 needs precision 64");
         StampDump sd;
         if (o.schedule == LT_SCHED_DIRECT) {
@@ -486,7 +487,10 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
             static const int long_iters = env_int("LT_D_LONG", 1024);
             if ((rc = sd.begin((size_t)(n_q / 64)))) return rc;
-            if constexpr (sizeof(T) == 8) { if (dp45) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats); }
+            if constexpr (sizeof(T) == 8) {
+                if (dp45 && !exact) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats);
+                if (exact) k_kerr_direct<T, Dp45<T, true>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats);
+            }
             if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats);
         } else {
             int cus;
@@ -501,10 +505,14 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             HIP_TRY(hipMemsetAsync(w.head, 0, sizeof(unsigned long long), s));
             if ((rc = sd.begin((size_t)qgrid * 4))) return rc;
             if constexpr (sizeof(T) == 8) {
-                if (dp45) // "long" is measured in step attempts: DP45 rays take ~50, not ~150
+                if (dp45 && !exact) // "long" is measured in step attempts: DP45 rays take ~50, not ~150
                     k_kerr_queue<T, Dp45<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint64_t)n_q,
                                                                  w.head, (uint32_t)chunk, (uint32_t)refill_min,
                                                                  (uint32_t)(long_steps / 3), sd.dev, kstats);
+                if (exact)
+                    k_kerr_queue<T, Dp45<T, true>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint64_t)n_q,
+                                                                       w.head, (uint32_t)chunk, (uint32_t)refill_min,
+                                                                       (uint32_t)(long_steps / 3), sd.dev, kstats);
             }
             if (!dp45)
                 k_kerr_queue<T, Rk4<T>><<<qgrid, 256, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, (uint64_t)n_q, w.head,
@@ -521,10 +529,11 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
 static int check_opts(const lt_metric *metric, lt_opts *o)
 {
     if (o->precision != 32 && o->precision != 64) return fail(LT_ERR_INVALID_ARG, "precision must be 32 or 64");
-    if (metric->kind == LT_METRIC_KERR && o->integrator == LT_INTEGRATOR_DP45 && o->precision != 64)
+    if (metric->kind == LT_METRIC_KERR && (o->integrator == LT_INTEGRATOR_DP45 || o->integrator == LT_INTEGRATOR_DP45_EXACT) &&
+        o->precision != 64)
         return fail(LT_ERR_UNSUPPORTED,
                     "DP45 at the reference tolerances needs float64 (rtol 1e-8 is below float32 epsilon)");
-    if (o->integrator != LT_INTEGRATOR_DP45 && o->integrator != LT_INTEGRATOR_RK4)
+    if (o->integrator != LT_INTEGRATOR_DP45 && o->integrator != LT_INTEGRATOR_RK4 && o->integrator != LT_INTEGRATOR_DP45_EXACT)
         return fail(LT_ERR_INVALID_ARG, "unknown integrator %d", o->integrator);
     if (o->schedule != LT_SCHED_DIRECT && o->schedule != LT_SCHED_QUEUE)
         return fail(LT_ERR_INVALID_ARG, "unknown schedule %d", o->schedule);
@@ -551,7 +560,7 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     if ((rc = check_opts(metric, &o))) return rc;
     MetricConsts mc;
     if ((rc = make_metric(metric, cam->r_obs, cam->theta_obs, o.h_max, &mc))) return rc;
-    if (metric->kind == LT_METRIC_KERR && o.integrator == LT_INTEGRATOR_DP45) { mc.evals_fixed = 1; mc.evals_per_step = 6; }
+    if (metric->kind == LT_METRIC_KERR && o.integrator != LT_INTEGRATOR_RK4) { mc.evals_fixed = 1; mc.evals_per_step = 6; }
 
     CamConsts c;
     memset(&c, 0, sizeof(c));
@@ -980,7 +989,7 @@ extern "C" int lt_trace_batch_kerr(double M, double a, double r_obs, const doubl
     if ((rc = check_opts(&m, &o))) return rc;
     MetricConsts mc;
     if ((rc = make_metric(&m, r_obs, theta_obs, 0.0, &mc))) return rc;
-    if (integrator == LT_INTEGRATOR_DP45) { mc.evals_fixed = 1; mc.evals_per_step = 6; }
+    if (integrator != LT_INTEGRATOR_RK4) { mc.evals_fixed = 1; mc.evals_per_step = 6; }
     return trace_batch(mc, o, lambda_max, alphas, thetas, axis_refines, n, out_fa, out_w, out_status, out_rhs_evals);
 }
 

@@ -57,10 +57,18 @@ template <typename T> struct Dp45State {
     uint32_t steps; // step attempts (accepted + rejected), metrics.py:454
 };
 
-template <typename T> struct Dp45 {
+// EXACT_CTRL = false: the step-size controller (error-scale reciprocal, err^-0.2) runs in float32 without the
+// transcendental unit -- step sizes follow the reference's to ~1e-7 relative, and the few accept / reject
+// decisions that sit within 1e-7 of err_norm = 1 can differ from the reference's (RHS-evaluation counts equal on
+// >= 99.9 % of rays, final_alpha to a few 1e-9).  EXACT_CTRL = true (LT_INTEGRATOR_DP45_EXACT): the controller as
+// the reference writes it (metrics.py:506-522, :560-564) in float64 -- division by the error scale, sqrt,
+// err_norm ** (-0.2) -- for renders whose accept / reject sequence must be the reference's.
+template <typename T, bool EXACT_CTRL = false> struct Dp45 {
     using State = Dp45State<T>;
     static constexpr int EVALS_FIXED = 1, EVALS_PER_STEP = 6;
-    static constexpr int MIN_WAVES_PER_SIMD = 2; // hold the register allocation at 256 (it sits just above)
+    // hold the register allocation at 256 (it sits just above); the float64 pow of the exact controller does not fit
+    // there without spilling, so that variant runs one wave per SIMD
+    static constexpr int MIN_WAVES_PER_SIMD = EXACT_CTRL ? 1 : 2;
 
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, T p_r, T p_th)
     {
@@ -143,7 +151,7 @@ template <typename T> struct Dp45 {
             T sc = atol + rtol * M<T>::max(M<T>::abs(y[i]), M<T>::abs(nxt[i]));
             // ei / sc with a float reciprocal (relative error 1e-7): the error norm only gates accept / reject
             // and scales h; a float64 division is ~25 instructions, five of them per attempt
-            T q = ei * (T)M<float>::rcp_pos((float)sc);
+            T q = EXACT_CTRL ? ei / sc : ei * (T)M<float>::rcp_pos((float)sc);
             err_sq += q * q;
         }
     }
@@ -179,8 +187,19 @@ template <typename T> struct Dp45 {
             return s.h < h_min ? EV_INVALID : EV_RUNNING;
         }
         // err_norm = sqrt(err_sq / 5); err_norm^(-0.2) = (err_sq / 5)^(-0.1)
-        const T grow = T(0.9) * (T)pow_minus_tenth((float)(err_sq * T(0.2)));
-        if (err_sq > T(5)) { // err_norm > 1: reject, metrics.py:516-522
+        T grow;
+        bool reject, tiny;
+        if (EXACT_CTRL) {
+            const double err_norm = __builtin_sqrt((double)err_sq / 5.0);          // metrics.py:514
+            grow = (T)(0.9 * pow(err_norm, -0.2));                                  // metrics.py:518, :564
+            reject = err_norm > 1.0;
+            tiny = err_norm < 1e-10;
+        } else {
+            grow = T(0.9) * (T)pow_minus_tenth((float)(err_sq * T(0.2)));
+            reject = err_sq > T(5);
+            tiny = err_sq < T(5e-20);
+        }
+        if (reject) { // err_norm > 1: reject, metrics.py:516-522
             s.h *= M<T>::max(T(0.2), grow);
             return s.h < h_min ? EV_INVALID : EV_RUNNING;
         }
@@ -204,7 +223,7 @@ template <typename T> struct Dp45 {
         for (int i = 0; i < 5; ++i) s.k1[i] = k7[i];
         s.s0 = sn; s.c0 = cn; // FSAL for the trigonometry too
         s.lam += h;
-        s.h = (err_sq < T(5e-20)) ? h * T(5) : h * M<T>::min(T(5), grow); // err_norm < 1e-10, metrics.py:561-564
+        s.h = tiny ? h * T(5) : h * M<T>::min(T(5), grow); // err_norm < 1e-10, metrics.py:561-564
         return EV_RUNNING;
     }
 };

@@ -349,7 +349,7 @@ if __name__ == "__main__":
     ap.add_argument("--output", default="lensed_image.png")
     ap.add_argument("--synthetic", type=int, nargs=2, metavar=("W", "H"), help="use a seeded synthetic background")
     ap.add_argument("--staged", action="store_true", help="run the reference's three stages one by one")
-    ap.add_argument("--integrator", choices=["rk4", "dp45"], default=None)
+    ap.add_argument("--integrator", choices=["rk4", "dp45", "dp45_exact"], default=None)
     ap.add_argument("--precision", type=int, choices=[32, 64], default=None)
     ap.add_argument("--schedule", choices=["direct", "queue"], default=None)
     args = ap.parse_args()

@@ -15,14 +15,14 @@ LIB_PATH = os.environ.get("LTRACE_LIB", os.path.join(_HERE, "lib", "libltrace_hi
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NO_DEVICE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 METRIC_SCHWARZSCHILD, METRIC_KERR = 0, 1
-INTEGRATOR_DP45, INTEGRATOR_RK4 = 0, 1
+INTEGRATOR_DP45, INTEGRATOR_RK4, INTEGRATOR_DP45_EXACT = 0, 1, 2
 SCHED_DIRECT, SCHED_QUEUE = 0, 1
 STAT_RAYS, STAT_STEPS, STAT_RHS_EVALS, STAT_ESCAPED, STAT_CAPTURED, STAT_INVALID = range(6)
 STAT_WAVE_ITERS, STAT_WAVES, STAT_CLK_CYCLES, STAT_CLK_TICKS = 6, 7, 8, 9
 STAT_BG_TILES_LDS, STAT_BG_TILES_GLOBAL = 10, 11
 STAT_WORDS = 16
 
-INTEGRATORS = {"dp45": INTEGRATOR_DP45, "rk4": INTEGRATOR_RK4}
+INTEGRATORS = {"dp45": INTEGRATOR_DP45, "rk4": INTEGRATOR_RK4, "dp45_exact": INTEGRATOR_DP45_EXACT}
 SCHEDULES = {"direct": SCHED_DIRECT, "queue": SCHED_QUEUE}
 
 

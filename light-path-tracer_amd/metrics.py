@@ -14,7 +14,7 @@ impact parameters, the 8-D Hamiltonian right-hand side consumed by
 scipy.solve_ivp in geodesic_tracer.py) is plain numpy.
 
 Extra, backend-only knobs (keyword arguments with reference-compatible defaults
-absent): integrator = 'rk4' | 'dp45', precision = 32 | 64, schedule =
+absent): integrator = 'rk4' | 'dp45' | 'dp45_exact', precision = 32 | 64, schedule =
 'direct' | 'queue'.
 """
 from abc import ABC, abstractmethod
@@ -155,7 +155,7 @@ class Kerr(Metric):
         self.r_plus = M + np.sqrt(M**2 - a**2)
         self.integrator = DEFAULT_KERR_INTEGRATOR if integrator is None else integrator
         self.precision = DEFAULT_PRECISION if precision is None else precision
-        if self.integrator == "dp45":
+        if self.integrator in ("dp45", "dp45_exact"):
             self.precision = 64
         self.schedule = DEFAULT_SCHEDULE if schedule is None else schedule
 
