@@ -18,6 +18,8 @@ float64 operations and stay on the host.  No CPU tracer exists in this package.
 """
 from time import perf_counter
 
+import os
+
 import numpy as np
 
 import ltrace
@@ -196,12 +198,20 @@ def render_lensed_image(source_image, alpha_lookup, final_alpha_lookup, winding_
 
 def render_frame(source_image, metric, r_obs, fov, psi=(0.0, 0.0), theta_obs=np.pi / 2, integrator=None,
                  precision=None, schedule=None, tb_symmetry=False, render_loop_around=False,
-                 want=("fa", "winding", "rgb")):
+                 want=("fa", "winding", "rgb"), gpus=1, devices=None):
     """Fused path (lt_render): all three stages in one GPU call.  source_image None -> shadow render
-    (escaped = white).  Returns dict with 'fa', 'winding', 'rgb', ... and 'stats'."""
+    (escaped = white).  Returns dict with 'fa', 'winding', 'rgb', ... and 'stats'.
+    gpus > 1: the frame's rows are split block-cyclically over that many devices of this node
+    (lt_render_multi; the reference's top/bottom mirror needs the whole frame on one device)."""
     if source_image is None:
         raise ValueError("render_frame needs a background; for a shadow use black_hole_shadow.render_traced")
-    shape = np.asarray(source_image).shape[:2]
+    source_image = np.asarray(source_image)
+    if source_image.ndim == 3 and source_image.shape[2] == 4:
+        # RGBA input (a PNG background): the reference's renderer cannot colour winding pixels of a 4-channel image
+        # (it assigns 3-channel WINDING_COLORS, image_lens.py:329-331) and turns black / magenta pixels transparent;
+        # the colour planes are what is lensed here
+        source_image = source_image[..., :3]
+    shape = source_image.shape[:2]
     kerr = not metric.is_spherically_symmetric
     met = ltrace.Metric(ltrace.METRIC_KERR if kerr else ltrace.METRIC_SCHWARZSCHILD, 0, float(metric.M),
                         float(getattr(metric, "a", 0.0)))
@@ -211,7 +221,14 @@ def render_frame(source_image, metric, r_obs, fov, psi=(0.0, 0.0), theta_obs=np.
         schedule=schedule or getattr(metric, "schedule", "direct"),
         tb_symmetry=int(bool(tb_symmetry)), loop_around=int(bool(render_loop_around)),
         axis_refine_frac=Y_AXIS_REFINE_FRAC)
-    return ltrace.render(_camera(shape, fov, psi, r_obs, theta_obs), met, opts, background=source_image, want=want)
+    cam = _camera(shape, fov, psi, r_obs, theta_obs)
+    if gpus and gpus > 1:
+        if tb_symmetry:
+            raise ValueError("tb_symmetry (the reference's top/bottom mirror) needs gpus == 1")
+        if devices is None and os.environ.get("LT_MULTI_DEVICES"):   # e.g. "0,0": rehearse 2 partitions on one GPU
+            devices = [int(x) for x in os.environ["LT_MULTI_DEVICES"].split(",")]
+        return ltrace.render_multi(cam, met, opts, gpus, devices=devices, background=source_image, want=want)
+    return ltrace.render(cam, met, opts, background=source_image, want=want)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -269,7 +286,7 @@ def write_png_rgba8(path, rgba, level=1):
 
 def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_fov_deg=40.0,
          image_path="image.jpg", output_path="lensed_image.png", synthetic=None, staged=False,
-         integrator=None, precision=None, schedule=None):
+         integrator=None, precision=None, schedule=None, gpus=1, full_trace=False):
     import matplotlib.image as mpimg
 
     if metric is None:
@@ -286,6 +303,9 @@ def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_f
         img = mpimg.imread(image_path)
         if img.dtype == np.uint8:
             img = img.astype(np.float32) / 255.0
+        if img.ndim == 3 and img.shape[2] == 4:
+            print("Background has an alpha channel: lensing its RGB planes (see render_frame)")
+            img = np.ascontiguousarray(img[..., :3])
     timings["load_image"] = perf_counter() - t0
     height, width = img.shape[:2]
     print(f"Image: {width}x{height}")
@@ -316,9 +336,15 @@ def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_f
         lensed = render_lensed_image(img, alpha_lookup, fa, wd, alpha_crit, fov, False, psi=psi)
         timings["render"] = perf_counter() - t0
     else:
-        print("Fused GPU render (pixel -> ray -> colour)...")
+        # The reference traces the top half of the frame and mirrors it whenever the observer is equatorial and the
+        # hole is not offset vertically (image_lens.py:218-220, :272-276 -- off by one row, quirk Q1).  Default: do
+        # as the reference does, so that `python image_lens.py --a 0.9` gives the reference's picture; --full-trace
+        # (and every multi-GPU render) traces every row instead.
+        mirror = (not full_trace) and gpus <= 1 and not metric.is_spherically_symmetric and abs(psi[0]) <= 1e-8
+        print(f"Fused GPU render (pixel -> ray -> colour) on {max(gpus, 1)} GPU(s); rows: "
+              + ("top half traced, bottom half mirrored as in the reference" if mirror else "every row traced"))
         t0 = perf_counter()
-        out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=False, want=("rgb", "rgba"))
+        out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=mirror, want=("rgb", "rgba"), gpus=gpus)
         timings["render"] = perf_counter() - t0
         timings["gpu_integrate_ms"] = out["stats"]["integrate_ms"]
         lensed, total, traced = out["rgb"], out["stats"]["rays"], out["stats"]["rays"]
@@ -352,7 +378,11 @@ if __name__ == "__main__":
     ap.add_argument("--integrator", choices=["rk4", "dp45", "dp45_exact"], default=None)
     ap.add_argument("--precision", type=int, choices=[32, 64], default=None)
     ap.add_argument("--schedule", choices=["direct", "queue"], default=None)
+    ap.add_argument("--gpus", type=int, default=1, help="split the frame's rows over this many GPUs of the node")
+    ap.add_argument("--full-trace", action="store_true",
+                    help="trace every row instead of the reference's top-half trace + mirror (Kerr, equatorial observer)")
     args = ap.parse_args()
     main(M=args.M, a=args.a, r_obs_mult=args.r_obs, psi=(np.radians(args.psi_y), np.radians(args.psi_x)),
          vertical_fov_deg=args.fov_v, image_path=args.image, output_path=args.output, synthetic=args.synthetic,
-         staged=args.staged, integrator=args.integrator, precision=args.precision, schedule=args.schedule)
+         staged=args.staged, integrator=args.integrator, precision=args.precision, schedule=args.schedule,
+         gpus=args.gpus, full_trace=args.full_trace)

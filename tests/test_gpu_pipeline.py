@@ -128,6 +128,42 @@ def test_cli_main_runs_end_to_end(tmp_path, capsys):
     np.testing.assert_array_equal(staged[:32], img[:32])
 
 
+def test_cli_default_is_the_reference_mirror_and_flags(tmp_path, capsys, monkeypatch):
+    """`python image_lens.py --a 0.9` must give the reference's picture: the reference traces the top half and mirrors
+    it (image_lens.py:218-220, :272-276, off by one row: quirk Q1), which only the staged path used to reproduce.
+    Default fused == staged; --full-trace differs from it exactly where the mirror is off by one; --gpus 2 (rehearsed
+    on one device) equals the full trace; an RGBA background is lensed by its colour planes."""
+    kw = dict(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), integrator="rk4", precision=32)
+    default = image_lens.main(output_path=str(tmp_path / "a.png"), **kw)
+    text = capsys.readouterr().out
+    assert "bottom half mirrored as in the reference" in text
+    staged = image_lens.main(output_path=str(tmp_path / "b.png"), staged=True, **kw)
+    np.testing.assert_array_equal(default, staged)
+    full = image_lens.main(output_path=str(tmp_path / "c.png"), full_trace=True, **kw)
+    assert "every row traced" in capsys.readouterr().out
+    assert np.array_equal(full[:32], default[:32]) and not np.array_equal(full[33:], default[33:])
+    monkeypatch.setenv("LT_MULTI_DEVICES", "0,0")
+    two = image_lens.main(output_path=str(tmp_path / "d.png"), gpus=2, **kw)
+    assert "on 2 GPU(s)" in capsys.readouterr().out
+    np.testing.assert_array_equal(two, full)
+    # RGBA background
+    import matplotlib.image as mpimg
+    bg = image_lens.synthetic_background(64, 96, 0)
+    rgba = np.concatenate([bg, np.ones((64, 96, 1), np.float32)], axis=-1)
+    mpimg.imsave(str(tmp_path / "bg.png"), rgba)
+    from_png = image_lens.main(a=0.9, r_obs_mult=100.0, image_path=str(tmp_path / "bg.png"), output_path=str(tmp_path / "e.png"),
+                               integrator="rk4", precision=32)
+    assert "alpha channel" in capsys.readouterr().out and from_png.shape == (64, 96, 3)
+    planes = np.ascontiguousarray(mpimg.imread(str(tmp_path / "bg.png"))[..., :3])     # what the PNG round trip kept
+    vfov = np.radians(40.0)
+    fov = (2 * np.arctan(np.tan(vfov / 2) * 96 / 64), vfov)
+    same = image_lens.render_frame(planes, metrics.Kerr(1.0, 0.9, integrator="rk4", precision=32), 100.0, fov, tb_symmetry=True)
+    np.testing.assert_array_equal(from_png, same["rgb"])
+    rgba_in = image_lens.render_frame(np.concatenate([planes, np.ones((64, 96, 1), np.float32)], -1),
+                                      metrics.Kerr(1.0, 0.9, integrator="rk4", precision=32), 100.0, fov, tb_symmetry=True)
+    np.testing.assert_array_equal(rgba_in["rgb"], same["rgb"])
+
+
 def test_traced_shadow_matches_oracle():
     S = metrics.Schwarzschild(1.0)
     img, status, stats = black_hole_shadow.render_traced(S, 256, 256)
