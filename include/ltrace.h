@@ -259,9 +259,9 @@ void lt_default_dense_opts(lt_dense_opts *o);
 #define LT_TRACK_FAILED (-1)     /* step size underflow (solve_ivp status -1)       */
 #define LT_TRACK_ATTEMPT_LIMIT (-2)
 
-/* HOST pointers.  state0 (n, 8).  Records are point-major so that device stores coalesce:
- *   out_t (max_points, n), out_y (max_points, 8, n): track i's k-th point is out_t[k*n + i],
- *   out_y[(k*8 + c)*n + i] -- solution.t[k], solution.y[c, k] of the reference.
+/* HOST pointers.  state0 (n, 8).  Records are track-major, the reference's solution.t / solution.y per track:
+ *   out_t (n, max_points), out_y (n, max_points, 8): track i's k-th point is out_t[i*max_points + k],
+ *   out_y[(i*max_points + k)*8 + c] -- solution.t[k], solution.y[c, k].  (Version 100 wrote them point-major.)
  *   out_count (n): points of the complete record.  If it exceeds max_points only the first
  *   max_points - 1 points are kept and the last slot holds the final point.
  *   out_status (n): LT_TRACK_*.   out_nfev (n): right-hand-side evaluations (solution.nfev). */

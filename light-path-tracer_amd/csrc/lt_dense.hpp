@@ -10,9 +10,12 @@
 // on an RMS norm, Shampine's 4th-order dense output, Brent's method for the event time -- so that the
 // step sequence (point count, nfev) equals solve_ivp's and the points agree to ~1e-9.
 //
-// Record layout: point-major, track-minor --  t[p * n + i],  y[(p * 8 + c) * n + i] --
-// so that the 64 tracks of a wavefront write 64 consecutive doubles per store instruction whenever
-// they are at the same point index (they mostly are: max_step paces every track alike).
+// Record layout: track-major --  t[i * max_points + p],  y[(i * max_points + p) * 8 + c] -- the
+// layout of the reference's solution.t / solution.y per track.  Every lane appends one aligned 64-byte segment
+// (four 16-byte stores) and one double per accepted point to ITS OWN record, so lanes need not be at the same
+// point index: a lane that repeats a rejected attempt falls a point behind its neighbours without breaking
+// anybody's store pattern.  (Round 1 used a point-major layout that coalesced only while all 64 tracks of a
+// wavefront advanced in lockstep -- which made every lane wait for every rejected attempt of any other lane.)
 #pragma once
 #include "lt_device.hpp"
 
@@ -140,14 +143,31 @@ __device__ inline double brent_root(double r_old, double t_old, double h, const 
 }
 
 struct DenseOut {
-    double *t;        // (max_points, n)
-    double *y;        // (max_points, 8, n)
+    double *t;        // (n, max_points)
+    double *y;        // (n, max_points, 8)
     int32_t *count;   // points a complete record holds (> max_points: truncated, last slot = final point)
     int8_t *status;   // 1 capture event, 2 escape event, 0 lambda_max reached, -1 step size underflow, -2 attempt limit
     int32_t *nfev;    // right-hand-side evaluations, counted like solve_ivp's nfev
 };
 
-__global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o)
+#ifndef LT_DENSE_WAVES
+#define LT_DENSE_WAVES 2 // waves per SIMD the register allocation is held to (measured: DESIGN.md 10)
+#endif
+
+// One track per lane.  Loop structure: solve_ivp's step is "repeat the attempt until it is accepted, then look
+// for events"; written like that for 64 tracks at once (round 1), every lane waits while any other lane repeats an
+// attempt and while any other lane locates its terminal event (Brent's method: several attempts' worth of
+// instructions, once per track, the 64 tracks of a wave one after the other) -- measured lane utilisation 0.47.
+// Here one loop iteration is ONE attempt of every lane: a lane that rejects retries in the next iteration while
+// its neighbours go on with their next step (track-major records make that free), and a lane whose accepted step
+// contains the terminal event leaves the loop; events are located after the loop by all lanes of the wave at the
+// same time.  Each lane performs exactly the operations it did before, in the same order: results are
+// bit-identical to round 1's.  What remains is the spread of track LENGTHS inside a wave: utilisation 0.59 against a
+// bound of 0.63 for one track per lane (tools/dense_lane_stats.py).  A persistent-wave variant that refills idle
+// lanes from a track queue was built and measured: utilisation 0.73, 7 % fewer instructions, but
+// 11 % MORE time -- its service code (event location, track start-up) runs at 8/64 lanes and the denser stream
+// clocks lower -- so it is not the kernel that ships.
+__global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o)
 {
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (i >= k.n) return;
@@ -174,10 +194,15 @@ __global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const dou
     int32_t n_pts = 0, nfev = 0;
     int status = 0;
     auto push = [&](double tt, const double *yy) {
-        int64_t slot = n_pts < k.max_points ? n_pts : k.max_points - 1;
-        o.t[slot * k.n + i] = tt;
+        const int64_t slot = i * k.max_points + (n_pts < k.max_points ? n_pts : k.max_points - 1);
+#ifndef LT_DENSE_NOSTORE // (diagnostic builds only: the kernel without its record stores)
+        o.t[slot] = tt;
+        double2 *rec = reinterpret_cast<double2 *>(o.y + slot * 8); // 64-byte aligned (hipMalloc'd base, 64 B per point)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) o.y[(slot * 8 + c) * k.n + i] = yy[c];
+        for (int c = 0; c < 4; ++c) rec[c] = make_double2(yy[2 * c], yy[2 * c + 1]);
+#else
+        if (tt == -12345.678) o.t[slot] = yy[0] + yy[1] + yy[2] + yy[3] + yy[4] + yy[5] + yy[6] + yy[7];
+#endif
         ++n_pts;
     };
     push(t, y);
@@ -206,89 +231,113 @@ __global__ void __launch_bounds__(64, 2) k_dense_tracks(DenseConsts k, const dou
     }
     double g_in = y[1] - r_in, g_out = y[1] - r_out;
     int32_t attempts = 0;
+    // The six stages of one attempt from (y, f, s0, c0) with step hh: k3..k7, the candidate yn and its trigonometry.
+    auto stages = [&](double hh, double *yn, double *k3, double *k4, double *k5, double *k6, double *k7) {
+        double k2[8], tmp[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * hh;
+        rhs8_near(k, tmp, y[2], s0, c0, k2, ss, cc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * hh;
+        rhs8_near(k, tmp, y[2], s0, c0, k3, ss, cc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * hh;
+        rhs8_near(k, tmp, y[2], s0, c0, k4, ss, cc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * hh;
+        rhs8_near(k, tmp, y[2], s0, c0, k5, ss, cc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * hh;
+        rhs8_near(k, tmp, y[2], s0, c0, k6, ss, cc);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) yn[c] = y[c] + hh * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
+        rhs8_near(k, yn, y[2], s0, c0, k7, sn, cn);
+    };
+    double h = 0, t_new = 0;
+    double min_step = 0;
+    bool new_step = true, rejected = false, hit_in = false, hit_out = false;
     while (t != k.lambda_max) {
-        const double min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
-        h_abs = h_abs > k.max_step ? k.max_step : (h_abs < min_step ? min_step : h_abs);
-        bool rejected = false, failed = false;
-        double h, t_new, yn[8], k2[8], k3[8], k4[8], k5[8], k6[8], k7[8], tmp[8];
-        for (;;) {
-            if (h_abs < min_step || ++attempts > k.max_attempts) { failed = true; break; }
-            t_new = t + h_abs;
-            if (t_new - k.lambda_max > 0) t_new = k.lambda_max;
-            h = t_new - t;
-            h_abs = fabs(h);
+        if (new_step) {
+            min_step = 10.0 * fabs(nextafter(t, INFINITY) - t);
+            h_abs = h_abs > k.max_step ? k.max_step : (h_abs < min_step ? min_step : h_abs);
+            rejected = false;
+            new_step = false;
+        }
+        if (h_abs < min_step || ++attempts > k.max_attempts) { status = attempts > k.max_attempts ? -2 : -1; break; }
+        t_new = t + h_abs;
+        if (t_new - k.lambda_max > 0) t_new = k.lambda_max;
+        h = t_new - t;
+        h_abs = fabs(h);
+        double yn[8], k3[8], k4[8], k5[8], k6[8], k7[8];
+        stages(h, yn, k3, k4, k5, k6, k7);
+        nfev += 6;
+        double e[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * h;
-            rhs8_near(k, tmp, y[2], s0, c0, k2, ss, cc);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * h;
-            rhs8_near(k, tmp, y[2], s0, c0, k3, ss, cc);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * h;
-            rhs8_near(k, tmp, y[2], s0, c0, k4, ss, cc);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * h;
-            rhs8_near(k, tmp, y[2], s0, c0, k5, ss, cc);
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * h;
-            rhs8_near(k, tmp, y[2], s0, c0, k6, ss, cc);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) yn[c] = y[c] + h * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
-            rhs8_near(k, yn, y[2], s0, c0, k7, sn, cn);
-            nfev += 6;
-            double e[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                double ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * h;
-                e[c] = ec / (k.atol + fmax(fabs(y[c]), fabs(yn[c])) * k.rtol);
-            }
-            const double err = rms8(e);
-            if (err < 1.0) {
-                double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow_m02(err));
-                if (rejected) factor = fmin(1.0, factor);
-                h_abs *= factor;
-                break;
-            }
+        for (int c = 0; c < 8; ++c) {
+            double ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * h;
+            e[c] = ec / (k.atol + fmax(fabs(y[c]), fabs(yn[c])) * k.rtol);
+        }
+        const double err = rms8(e);
+        if (!(err < 1.0)) { // rejected: this lane retries in the next iteration with a smaller step
             h_abs *= fmax(0.2, 0.9 * pow_m02(err)); // a NaN norm shrinks by 0.2, as in scipy (max(0.2, nan))
             rejected = true;
+            continue;
         }
-        if (failed) { status = attempts > k.max_attempts ? -2 : -1; break; }
+        double factor = (err == 0.0) ? 10.0 : fmin(10.0, 0.9 * pow_m02(err));
+        if (rejected) factor = fmin(1.0, factor);
+        h_abs *= factor;
         const double gn_in = yn[1] - r_in, gn_out = yn[1] - r_out;
-        const bool hit_in = g_in >= 0 && gn_in <= 0, hit_out = g_out <= 0 && gn_out >= 0;
-        if (hit_in || hit_out) {
-            // dense output of this step, y(t) = y + h Q [x, x^2, x^3, x^4] with Q = K^T P: only the radius row is
-            // needed to locate the event; the other rows are formed one at a time afterwards (registers)
-            auto q_row = [&](int c, double *q) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    q[j] = f[c] * P[0][j] + k3[c] * P[2][j] + k4[c] * P[3][j] + k5[c] * P[4][j] + k6[c] * P[5][j] + k7[c] * P[6][j];
-            };
-            double Qr[4];
-            q_row(1, Qr);
-            double root_in = 0, root_out = 0;
-            if (hit_in) root_in = brent_root(y[1], t, h, Qr, r_in, t, t_new);
-            if (hit_out) root_out = brent_root(y[1], t, h, Qr, r_out, t, t_new);
-            const bool take_in = hit_in && (!hit_out || root_in <= root_out);
-            const double te = take_in ? root_in : root_out;
-            const double x = (te - t) / h, x2 = x * x, x3 = x2 * x, x4 = x3 * x;
-            double ye[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                double q[4];
-                q_row(c, q);
-                ye[c] = y[c] + h * (q[0] * x + q[1] * x2 + q[2] * x3 + q[3] * x4);
-            }
-            push(te, ye);
-            status = take_in ? 1 : 2;
-            break;
-        }
+        hit_in = g_in >= 0 && gn_in <= 0;
+        hit_out = g_out <= 0 && gn_out >= 0;
+        // terminal event inside this step: the lane leaves with (t, y, f, s0, c0, h) of the step's START; the event is
+        // located below, once for the whole wave
+        if (hit_in || hit_out) break;
         g_in = gn_in; g_out = gn_out;
         t = t_new;
 #pragma unroll
         for (int c = 0; c < 8; ++c) { y[c] = yn[c]; f[c] = k7[c]; }
         s0 = sn; c0 = cn;
         push(t, y);
+        new_step = true;
+    }
+    if (hit_in || hit_out) {
+        // The stages of the step that contains the event are formed AGAIN here (same inputs, same operations, same
+        // bits: one extra attempt per wave) rather than carried out of the loop -- 40 live float64 values would
+        // cost the loop its second wave per SIMD.
+        double yn[8], k3[8], k4[8], k5[8], k6[8], k7[8];
+        stages(h, yn, k3, k4, k5, k6, k7);
+        // dense output of that step, y(t) = y + h Q [x, x^2, x^3, x^4] with Q = K^T P: only the radius row is
+        // needed to locate the event; the other rows are formed one at a time afterwards (registers)
+        auto q_row = [&](int c, double *q) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                q[j] = f[c] * P[0][j] + k3[c] * P[2][j] + k4[c] * P[3][j] + k5[c] * P[4][j] + k6[c] * P[5][j] + k7[c] * P[6][j];
+        };
+        double Qr[4];
+        q_row(1, Qr);
+        // (one Brent call serves both kinds of lanes -- each with its own radius -- when no lane crossed both radii
+        // in the same step, which is the rule: the two calls used to run one after the other)
+        double root_in = 0, root_out = 0;
+        if (!__ballot(hit_in && hit_out)) {
+            const double root = brent_root(y[1], t, h, Qr, hit_in ? r_in : r_out, t, t_new);
+            root_in = root_out = root;
+        } else {
+            if (hit_in) root_in = brent_root(y[1], t, h, Qr, r_in, t, t_new);
+            if (hit_out) root_out = brent_root(y[1], t, h, Qr, r_out, t, t_new);
+        }
+        const bool take_in = hit_in && (!hit_out || root_in <= root_out);
+        const double te = take_in ? root_in : root_out;
+        const double x = (te - t) / h, x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        double ye[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double q[4];
+            q_row(c, q);
+            ye[c] = y[c] + h * (q[0] * x + q[1] * x2 + q[2] * x3 + q[3] * x4);
+        }
+        push(te, ye);
+        status = take_in ? 1 : 2;
     }
     o.count[i] = n_pts;
     o.status[i] = (int8_t)status;

@@ -90,7 +90,7 @@ def integrate_geodesics(metric, states0, lambda_max=1000.0, r_stop_inner=None, r
     out = []
     for i in range(s0.shape[0]):
         m = min(int(count[i]), int(max_points))
-        trk = Track(t[:m, i].copy(), np.ascontiguousarray(y[:m, :, i].T), int(status[i]), nfev[i], count[i] > max_points)
+        trk = Track(t[i, :m].copy(), np.ascontiguousarray(y[i, :m].T), int(status[i]), nfev[i], count[i] > max_points)
         out.append((trk, "captured" if trk.y[1, -1] <= 1.1 * r_in else "escaped"))
     return out
 

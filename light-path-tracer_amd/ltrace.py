@@ -383,15 +383,15 @@ def default_dense_opts(**kw):
 
 def integrate_dense(metric, state0, opts=None):
     """Batched integrate_geodesic (lt_integrate_dense): state0 (n, 8) ->
-    (t (max_points, n), y (max_points, 8, n), count (n,), status (n,), nfev (n,)).
-    Track i is t[:m, i], y[:m, :, i].T with m = min(count[i], max_points)."""
+    (t (n, max_points), y (n, max_points, 8), count (n,), status (n,), nfev (n,)).
+    Track i is t[i, :m], y[i, :m].T (= solution.t, solution.y of the reference) with m = min(count[i], max_points)."""
     o = opts or default_dense_opts()
     s0 = np.ascontiguousarray(state0, dtype=np.float64).reshape(-1, 8)
     n, mp = s0.shape[0], int(o.max_points)
     if mp < 2:
         raise LtraceError(ERR_INVALID_ARG, "max_points must be at least 2")
-    t = np.empty((mp, n), dtype=np.float64)
-    y = np.empty((mp, 8, n), dtype=np.float64)
+    t = np.empty((n, mp), dtype=np.float64)
+    y = np.empty((n, mp, 8), dtype=np.float64)
     count = np.zeros(n, dtype=np.int32)
     status = np.zeros(n, dtype=np.int8)
     nfev = np.zeros(n, dtype=np.int32)

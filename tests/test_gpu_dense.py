@@ -55,8 +55,8 @@ def test_tracks_match_reference_solve_ivp():
         assert count[0] == len(gt_) and nfev[0] == g["nfev"][i], f"track {i}: {count[0]} vs {len(gt_)} points"
         assert (status[0] in (1, 2)) == (g["ivp_status"][i] == 1)
         m = count[0]
-        np.testing.assert_allclose(t[:m, 0], gt_, rtol=0, atol=1e-7)
-        err = np.max(np.abs(y[:m, :, 0].T - gy) / (1 + np.abs(gy)))
+        np.testing.assert_allclose(t[0, :m], gt_, rtol=0, atol=1e-7)
+        err = np.max(np.abs(y[0, :m].T - gy) / (1 + np.abs(gy)))
         worst = max(worst, err)
         assert err < 1e-8, f"track {i}"
     print(f"worst relative point difference vs solve_ivp: {worst:.2e}")
@@ -83,10 +83,10 @@ def test_batch_matches_oracle(kerr, a):
         if len(ot) == count[i] and onfev == nfev[i]:
             same_steps += 1
             m = count[i]
-            errs.append(np.max(np.abs(y[:m, :, i].T - oy) / (1 + np.abs(oy))))
+            errs.append(np.max(np.abs(y[i, :m].T - oy) / (1 + np.abs(oy))))
         else:  # an accept / reject decision within rounding of err = 1: the end point still agrees
             assert abs(int(count[i]) - len(ot)) <= 2
-            np.testing.assert_allclose(y[min(count[i], 700) - 1, :, i], oy[:, -1], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(y[i, min(count[i], 700) - 1], oy[:, -1], rtol=1e-6, atol=1e-6)
     assert same_steps >= n - 3, f"{n - same_steps} tracks took a different step sequence"
     errs = np.array(errs)
     print(f"a={a}: median {np.median(errs):.1e}  p99 {np.quantile(errs, 0.99):.1e}  max {errs.max():.1e};"
@@ -111,7 +111,7 @@ def test_large_batch_properties():
     assert np.all(count_full >= 30) and np.mean(count_full > MP) < 1e-3  # a few near-critical tracks orbit for long
     count = np.minimum(count_full, MP)
     idx = np.arange(n)
-    last = y[count - 1, :, idx]                         # (n, 8) final points (kept even when truncated)
+    last = y[idx, count - 1]                            # (n, 8) final points (kept even when truncated)
     r_in = 1.01 * (1 + np.sqrt(1 - a * a))
     target = np.where(status == 1, r_in, 100.0)
     assert np.max(np.abs(last[:, 1] - target)) < 1e-9   # the event radius, located to 4 eps by Brent's method
@@ -124,19 +124,19 @@ def test_large_batch_properties():
         terms = np.stack([-A / (S * D) * pt * pt, -4 * a * r / (S * D) * pt * pph, D / S * pr * pr, pth * pth / S,
                           (D - a * a * s2) / (S * D * s2) * pph * pph])
         return np.abs(terms.sum(0)) / np.abs(terms).sum(0)   # |2H| relative to the size of its terms
-    mid = y[count // 2, :, idx]
+    mid = y[idx, count // 2]
     h_mid, h_last = hamiltonian(mid), hamiltonian(last)
     print(f"relative null-condition residual: mid-track max {h_mid.max():.1e}, end max {h_last.max():.1e}")
     assert h_mid.max() < 1e-6 and h_last.max() < 1e-6
     # times strictly increase along every track
-    assert np.all(np.diff(t, axis=0)[np.arange(MP - 1)[:, None] < (count - 1)[None, :]] > 0)
+    assert np.all(np.diff(t, axis=1)[np.arange(MP - 1)[None, :] < (count - 1)[:, None]] > 0)
     # grouping: a permuted batch gives bit-identical tracks
     perm = rng.permutation(n)[:4096]
     t2, y2, c2, st2, nf2 = ltrace.integrate_dense(lm, s0[perm], o)
     assert np.array_equal(c2, count_full[perm]) and np.array_equal(st2, status[perm]) and np.array_equal(nf2, nfev[perm])
     for j in (0, 17, 4095):
         m = min(c2[j], MP)
-        assert np.array_equal(y2[:m, :, j], y[:m, :, perm[j]]) and np.array_equal(t2[:m, j], t[:m, perm[j]])
+        assert np.array_equal(y2[j, :m], y[perm[j], :m]) and np.array_equal(t2[j, :m], t[perm[j], :m])
 
 
 def test_truncation_and_range_end():
@@ -147,10 +147,10 @@ def test_truncation_and_range_end():
     cut = ltrace.integrate_dense(lm, s0, ltrace.default_dense_opts(max_points=16))
     assert np.array_equal(full[2], cut[2]) and np.all(cut[2] > 16)       # counts report the complete record
     for i in range(2):
-        assert np.array_equal(cut[1][:15, :, i], full[1][:15, :, i])       # first max_points - 1 points kept
-        assert np.array_equal(cut[1][15, :, i], full[1][full[2][i] - 1, :, i])  # last slot = final point
+        assert np.array_equal(cut[1][i, :15], full[1][i, :15])             # first max_points - 1 points kept
+        assert np.array_equal(cut[1][i, 15], full[1][i, full[2][i] - 1])   # last slot = final point
     t, y, count, status, nfev = ltrace.integrate_dense(lm, s0, ltrace.default_dense_opts(lambda_max=30.0))
-    assert np.all(status == ltrace.TRACK_RANGE_END) and np.all(t[count - 1, np.arange(2)] == 30.0)
+    assert np.all(status == ltrace.TRACK_RANGE_END) and np.all(t[np.arange(2), count - 1] == 30.0)
 
 
 def test_host_mirror_trace_rays_matches_scipy_path():

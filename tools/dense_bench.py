@@ -51,8 +51,8 @@ def main():
     a = float(sys.argv[3]) if len(sys.argv) > 3 else 0.9
     dev = torch.device("cuda:0")
     s0 = torch.from_numpy(states(n, a)).to(dev)
-    t = torch.empty((mp, n), dtype=torch.float64, device=dev)
-    y = torch.empty((mp, 8, n), dtype=torch.float64, device=dev)
+    t = torch.empty((n, mp), dtype=torch.float64, device=dev)
+    y = torch.empty((n, mp, 8), dtype=torch.float64, device=dev)
     cnt = torch.zeros(n, dtype=torch.int32, device=dev)
     st = torch.zeros(n, dtype=torch.int8, device=dev)
     nf = torch.zeros(n, dtype=torch.int32, device=dev)
