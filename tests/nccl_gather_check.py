@@ -1,0 +1,51 @@
+"""One rank of the multi-GPU parity check (started by tests/test_gpu_multi.py, one process per GPU): every rank renders its
+block-cyclic row partition, the RGBA8 framebuffer is gathered to rank 0 over RCCL (sharding.FrameGather, backend nccl)
+and un-permuted there; rank 0 also renders the whole frame alone and the two must agree byte for byte."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "light-path-tracer_amd")):
+    sys.path.insert(0, p)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402  (before ltrace: see tests/hipmini.py)
+import torch.distributed as dist  # noqa: E402
+
+import ltrace               # noqa: E402
+import sharding             # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", device_id=dev)
+    W, H, rb = 1000, 777, 16                      # ragged: partitions of unequal size, last block short
+    fov_v = np.radians(40.0)
+    cam = ltrace.Camera(W, H, 2 * np.arctan(np.tan(fov_v / 2) * W / H), fov_v, 0.02, -0.03, 50.0, np.pi / 2)
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    stream = torch.cuda.current_stream(dev)
+    fg = sharding.FrameGather(H, W, 4, torch.uint8, dev, rb, world, rank)
+    o = ltrace.default_opts(precision=32, n_parts=world, part=rank, row_block=rb)
+    o.stream = stream.cuda_stream
+    for _ in range(2):                            # buffers are reused frame after frame
+        ltrace.render_dev(cam, met, o, d_rgba=fg.local.data_ptr())
+        full = fg.gather(stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    ok = True
+    if rank == 0:
+        whole = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+        o1 = ltrace.default_opts(precision=32)
+        o1.stream = stream.cuda_stream
+        ltrace.render_dev(cam, met, o1, d_rgba=whole.data_ptr())
+        torch.cuda.synchronize(dev)
+        ok = bool(torch.equal(full, whole))
+        print(f"nccl gather over {world} ranks: frame {'identical' if ok else 'DIFFERS'}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
