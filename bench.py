@@ -86,7 +86,7 @@ def parse(argv=None):
     ap.add_argument("--pipelined-extra", type=int, default=3,
                     help="after the timed region, time the same K frames again with this many frames in flight and report it "
                          "as `pipelined` (0 / 1: skip)")
-    ap.add_argument("--bg-sampling", choices=["lds", "global"], default="lds", help="epilogue background path (LT_BG_*)")
+    ap.add_argument("--bg-sampling", choices=["lds", "global"], default="global", help="epilogue background path (LT_BG_*)")
     ap.add_argument("--backend", default=None, help="process-group backend (default nccl = RCCL; tests use gloo)")
     ap.add_argument("--stub-render", action="store_true",
                     help="CPU rehearsal of the launcher / gather path: no GPU, rows filled by a formula (tests only)")
@@ -157,8 +157,9 @@ def cpu_baseline(args, fov):
     benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame of the same
     camera.  One thread per usable CPU."""
     cores = usable_cpus()
-    os.environ["OMP_NUM_THREADS"] = str(cores)             # before libgomp is first initialised in this process
     from oracle import oracle
+    oracle.set_num_threads(cores, perf_build=True)         # (torch initialised libgomp long ago: the environment is not read again)
+    threads = oracle.lib_perf().lto_num_threads()
     kind = args.metric
     kw = dict(integrator="rk4" if args.integrator == "rk4" else "dp45", perf_build=True)
     oracle.lookup(kind, 1.0, args.a, args.r_obs, 64, 64, fov, fov, **kw)       # compiles; spins the threads up
@@ -172,11 +173,11 @@ def cpu_baseline(args, fov):
     t0 = time.perf_counter()
     r = oracle.lookup(kind, 1.0, args.a, args.r_obs, n, n, fov, fov, **kw)
     dt = time.perf_counter() - t0
-    return {"value": round(n * n / dt / 1e6, 4), "unit": "Mrays/s", "cores": oracle.num_threads(),
+    return {"value": round(n * n / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads,
             "host_cpus_visible": os.cpu_count(),
             "kind": "port (perf build: gcc " + " ".join(oracle.PERF_FLAGS[:3]) + ", built on this host)",
             "sample": f"{n}x{n} rays = every {stride}th pixel (x and y) of the {args.size}x{args.size} frame, "
-                      f"oracle {args.integrator} float64 + OpenMP on {oracle.num_threads()} threads, {dt:.1f} s",
+                      f"oracle {args.integrator} float64 + OpenMP on {threads} threads (the job's CPU quota), {dt:.1f} s",
             "mean_rhs_evals_per_ray": round(float(r["evals"].mean()), 1)}
 
 

@@ -865,4 +865,15 @@ int lto_num_threads(void)
     return 1;
 #endif
 }
+
+/* Number of OpenMP threads the batch loops use from now on (bench.py's cpu_baseline: one per usable CPU of the
+ * job, which on a shared host is fewer than the CPUs the process can see). */
+void lto_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 #endif /* !LTO_F32 */

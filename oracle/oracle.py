@@ -93,6 +93,7 @@ def lib_perf():
         L.lto_lookup.argtypes = lib().lto_lookup.argtypes
         L.lto_lookup.restype = C.c_int64
         L.lto_num_threads.restype = C.c_int
+        L.lto_num_threads.argtypes = []
         _LIB_PERF = L
     return _LIB_PERF
 
@@ -115,6 +116,14 @@ def lib32():
 
 def num_threads():
     return int(lib().lto_num_threads())
+
+
+def set_num_threads(n, perf_build=False):
+    """OpenMP threads of the batch loops (libgomp may have been initialised long before, e.g. by torch)."""
+    L = lib_perf() if perf_build else lib()
+    L.lto_set_num_threads.argtypes = [C.c_int]
+    L.lto_set_num_threads.restype = None
+    L.lto_set_num_threads(int(n))
 
 
 def kerr_rhs(state5, p_t, p_phi, M, a, r_plus):

@@ -4,11 +4,12 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 run() {
     echo "== bench.py $*"
-    python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" 2>/dev/null | tail -1 | python3 -c "
+    python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']; c = d['config']
 print(f\"{d['value']:.1f} Mrays/s  {d['ms_per_step']:.4f} ms/frame  integrate {r['avg_launch_ms']:.4f} ms  prologue/epilogue {r['other_kernels_ms']['prologue']:.3f}/{r['other_kernels_ms']['epilogue']:.3f} ms  \"
-      f\"{r['achieved']:.1f} of {r['peak']} {r['unit']} ({r['bound']}) frac {r['frac']:.3f}  steps/ray {c['mean_rk4_steps_per_ray']}  escaped/captured/invalid {c['escaped']}/{c['captured']}/{c['invalid']}\")"
+      f\"issue frac {r['frac']} (as-written {r['algorithmic_as_written']['of_peak']})  steps/ray {c['mean_rk4_steps_per_ray']}  escaped/captured/invalid {c['escaped']}/{c['captured']}/{c['invalid']}\"
+      + (f\"  pipelined x{d['pipelined']['frames_in_flight']}: {d['pipelined']['value']:.1f} Mrays/s\" if 'pipelined' in d else ''))"
 }
 run --metric schwarzschild --size 1024
 run --size 2048

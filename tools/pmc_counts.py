@@ -96,13 +96,23 @@ def main():
             text.append(f"   HBM: FETCH_SIZE {fetch_kb:.1f} KB x2 + WRITE_SIZE {write_kb:.1f} KB = {total / 1e6:.1f} MB per launch; algorithmic "
                         f"{j['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB; epilogue kernel FETCH x2 {cf.get(('epilogue', 'FETCH_SIZE'), 0) * 2048 / 1e6:.1f} MB, "
                         f"WRITE {cw.get(('epilogue', 'WRITE_SIZE'), 0) * 1024 / 1e6:.1f} MB")
+        if "background" in " ".join(args):
+            # the epilogue's background gather: L2 hit rate and fetched bytes, both sampling paths
+            for mode in ("global", "lds"):
+                jt, ct = profiled(tag + "_tcc_" + mode, ["TCC_HIT_sum", "TCC_MISS_sum"], args + ["--bg-sampling", mode])
+                jf2, cf2 = profiled(tag + "_fetch_" + mode, ["FETCH_SIZE"], args + ["--bg-sampling", mode])
+                if jt and jf2:
+                    hit, miss = ct.get(("epilogue", "TCC_HIT_sum"), 0), ct.get(("epilogue", "TCC_MISS_sum"), 0)
+                    text.append(f"   epilogue kernel, bg_sampling={mode}: {jt['roofline']['other_kernels_ms']['epilogue']} ms; L2 hit rate "
+                                f"{hit / max(hit + miss, 1):.3f} (TCC_HIT_sum {hit:.0f}, TCC_MISS_sum {miss:.0f}); FETCH_SIZE x2 "
+                                f"{cf2.get(('epilogue', 'FETCH_SIZE'), 0) * 2048 / 1e6:.1f} MB (records 536.9 MB + background 201.3 MB algorithmic); "
+                                f"16x16 tiles staged in LDS / global fallback: {jt['config'].get('bg_groups_lds')} / {jt['config'].get('bg_groups_global')}")
         for name, obj in (("valu_counts.json", valu), ("hbm_traffic.json", hbm)):
             with open(os.path.join(OUT, name), "w") as f:
                 json.dump(obj, f, indent=1)
         with open(os.path.join(OUT, "summary.txt"), "w") as f:
             f.write("\n".join(text) + "\n")
-        print(text[-2] if len(text) > 1 else text[-1], flush=True)
-        print(text[-1], flush=True)
+        print("\n".join(text[-4:]), flush=True)
 
 
 if __name__ == "__main__":
