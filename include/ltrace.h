@@ -132,6 +132,9 @@ int lt_set_device(int device);
  * (NULL) stream, like the reference's synchronous calls.  Buffers grow to the largest frame seen and are
  * then reused: nothing is allocated per call. */
 int lt_shutdown(void);
+/* Frees what the library holds for (current device, stream) after draining the stream: call it before destroying
+ * a stream that was used with the library (otherwise its buffers stay until lt_shutdown). */
+int lt_release_stream(void *stream);
 void lt_default_opts(lt_opts *o);
 
 /* ---- array-in / array-out twins of the reference batch drivers ---------------------- *

@@ -195,6 +195,33 @@ static int cu_count(int *out)
     return LT_OK;
 }
 
+// Frees what the library holds for (current device, stream): call it before destroying a stream that was used
+// with the library, or the buffers stay until lt_shutdown().
+extern "C" int lt_release_stream(void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    Ctx *c;
+    if ((rc = cur_ctx(&c))) return rc;
+    StreamSlot *found = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < c->slots.size(); ++i)
+            if (c->slots[i]->stream == (hipStream_t)stream) {
+                found = c->slots[i];
+                c->slots.erase(c->slots.begin() + (long)i);
+                break;
+            }
+    }
+    if (!found) return LT_OK;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    release(found->ws);
+    release(found->dev);
+    if (found->own_ok) for (auto &e : found->own.e) (void)hipEventDestroy(e);
+    delete found;
+    return LT_OK;
+}
+
 extern "C" int lt_shutdown(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "lt_device_count": (C.c_int, []),
     "lt_set_device": (C.c_int, [C.c_int]),
     "lt_shutdown": (C.c_int, []),
+    "lt_release_stream": (C.c_int, [C.c_void_p]),
     "lt_default_opts": (None, [C.POINTER(Opts)]),
     "lt_trace_batch_schw": (C.c_int, [C.c_double, C.c_double, C.c_void_p, C.c_int64, C.c_double, C.c_double,
                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -443,6 +444,11 @@ def timing_collect():
     n = C.c_int32()
     _check(load().lt_timing_collect(C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
     return dict(prologue_ms=a.value, integrate_ms=b.value, epilogue_ms=c.value, calls=n.value)
+
+
+def release_stream(stream_ptr):
+    """Free the library's buffers of (current device, stream) -- before the stream is destroyed."""
+    _check(load().lt_release_stream(C.c_void_p(stream_ptr) if stream_ptr else None))
 
 
 def shutdown():

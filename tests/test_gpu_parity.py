@@ -665,6 +665,14 @@ def test_two_streams_do_not_share_a_workspace():
     bf2, bw2 = np.full(al.size, np.nan), np.zeros(al.size, dtype=np.int64)
     ltrace.trace_batch_kerr(1.0, 0.9, 50.0, al, np.full(al.size, 0.7), np.pi / 2, 5000.0, None, bf2, bw2, precision=32)
     assert np.array_equal(bf, bf2, equal_nan=True) and np.array_equal(bw, bw2)
+    # a stream's buffers can be handed back before the stream is destroyed; the stream stays usable (they regrow)
+    for s in streams:
+        ltrace.release_stream(s.ptr)
+    ltrace.release_stream(streams[0].ptr)                     # twice: nothing left, still fine
+    ltrace.render_dev(cams[0], met, o, d_fa=fa.ptr, d_status=stt.ptr, d_steps=stp.ptr)
+    streams[0].synchronize()
+    assert np.array_equal(fa.get(), alone[0]["fa"], equal_nan=True)
+    ltrace.release_stream(streams[0].ptr)
 
 
 def test_render_multi_and_host_destinations():
