@@ -83,6 +83,12 @@ def parse(argv=None):
                     help="one GPU plays rank --emulate-part of an N-GPU run: renders only that row partition (no gather); "
                          "tools/part_bench.py uses it to project the N-GPU frame time from one GPU")
     ap.add_argument("--emulate-part", type=int, default=0)
+    ap.add_argument("--balance", choices=["cyclic", "cost"], default="cyclic",
+                    help="row blocks -> ranks: block-cyclic (default), or cost-weighted from one untimed frame's step counts "
+                         "(sharding.balance_blocks: the rank that owns the longest ray gets less of the bulk)")
+    ap.add_argument("--owner-file", default=None, help="(.npy, uint16) a row-block owner table to use as is (emulated ranks)")
+    ap.add_argument("--chain-cost", type=float, default=137500.0,
+                    help="--balance cost: lane-steps of bulk that take as long as one step of a lone ray (0.55 us / 4.0 ps)")
     ap.add_argument("--pipelined-extra", type=int, default=3,
                     help="after the timed region, time the same K frames again with this many frames in flight and report it "
                          "as `pipelined` (0 / 1: skip)")
@@ -329,7 +335,40 @@ def main(argv=None):
                         args.a if args.metric == "kerr" else 0.0)
     rb = args.row_block
     n_parts, part = (args.emulate_parts, args.emulate_part) if (args.emulate_parts and world == 1) else (world, rank)
-    rows_max = max(ltrace.local_rows(size, rb, n_parts, p) for p in range(n_parts))
+    owner = None
+    if args.owner_file:
+        owner = np.load(args.owner_file).astype(np.uint16)
+    elif args.balance == "cost" and n_parts > 1 and args.metric == "kerr":
+        # one untimed frame on the default partition: per-row-block step totals and longest ray, all-gathered; every rank
+        # then computes the same owner table
+        nb = (size + rb - 1) // rb
+        o0 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
+                                 row_block=rb, n_parts=n_parts, part=part)
+        o0.stream = torch.cuda.current_stream(dev).cuda_stream
+        r0 = ltrace.local_rows(size, rb, n_parts, part)
+        d_steps0 = torch.empty((r0, size), dtype=torch.int32, device=dev)
+        ltrace.render_dev(cam, met, o0, d_steps=d_steps0.data_ptr())
+        torch.cuda.synchronize(dev)
+        st = d_steps0.to(torch.int64)
+        mine_blocks = torch.from_numpy(ltrace.global_rows(size, rb, n_parts, part)[::rb] // rb).to(dev)
+        per_row_sum, per_row_max = st.sum(dim=1), st.max(dim=1).values
+        pad = (-r0) % rb
+        if pad:
+            per_row_sum = torch.cat([per_row_sum, per_row_sum.new_zeros(pad)])
+            per_row_max = torch.cat([per_row_max, per_row_max.new_zeros(pad)])
+        cost_t = torch.zeros(nb, dtype=torch.int64, device=dev)
+        chain_t = torch.zeros(nb, dtype=torch.int64, device=dev)
+        cost_t[mine_blocks] = per_row_sum.view(-1, rb).sum(dim=1)
+        chain_t[mine_blocks] = per_row_max.view(-1, rb).max(dim=1).values
+        if world > 1:
+            dist.all_reduce(cost_t, op=dist.ReduceOp.SUM)
+            dist.all_reduce(chain_t, op=dist.ReduceOp.SUM)
+        owner = sharding.balance_blocks(cost_t.cpu().numpy(), chain_t.cpu().numpy(), n_parts, chain_cost=args.chain_cost)
+        del d_steps0, st
+    if owner is not None:
+        rows_max = max(len(ltrace.owned_rows(size, rb, owner, p)) for p in range(n_parts))
+    else:
+        rows_max = max(ltrace.local_rows(size, rb, n_parts, p) for p in range(n_parts))
 
     # device buffers (torch owns the memory; the library only sees raw pointers); one set per frame in flight
     F = max(1, args.frames_in_flight)
@@ -344,10 +383,10 @@ def main(argv=None):
         for f in range(nf):
             st = torch.cuda.current_stream(dev) if nf == 1 else torch.cuda.Stream(dev)
             o = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
-                                    row_block=rb, n_parts=n_parts, part=part, timing=1,
+                                    row_block=rb, n_parts=n_parts, part=part, timing=1, block_owner=owner,
                                     bg_sampling=ltrace.BG_LDS_TILES if args.bg_sampling == "lds" else ltrace.BG_GLOBAL)
             o.stream = st.cuda_stream
-            fg = (sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank) if n_parts == world else
+            fg = (sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank, owner=owner) if n_parts == world else
                   sharding.FrameGather(rows_max, size, 4, torch.uint8, dev, rows_max, 1, 0))          # emulated rank: no gather
             out.append(dict(stream=st, opts=o, fg=fg,   # RGBA8 framebuffer
                             fa=torch.empty((rows_max, size), dtype=torch.float32, device=dev),
@@ -538,7 +577,9 @@ def main(argv=None):
             "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "rays_per_frame": rays_per_frame, "schedule": args.schedule, "build_id": bid, "profile_key": key,
-                       "row_partition": f"block-cyclic {rb} rows x {n_parts}" + (f" (emulated rank {part} on one GPU)" if n_parts != world else ""),
+                       "row_partition": (f"block-cyclic {rb} rows x {n_parts}" if owner is None else
+                                         f"cost-weighted {rb}-row blocks x {n_parts} (rows per rank "
+                                         f"{[len(ltrace.owned_rows(size, rb, owner, p)) for p in range(n_parts)]})") + (f" (emulated rank {part} on one GPU)" if n_parts != world else ""),
                        "gather": "rccl" if world > 1 else "none",
                        "frames_in_flight": F,
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),

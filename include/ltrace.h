@@ -84,6 +84,13 @@ typedef struct lt_opts {
     void *stream;            /* hipStream_t to launch on; NULL = the default stream */
     int32_t timing;          /* !=0: bracket each kernel with HIP events (lt_timing_collect) */
     int32_t bg_sampling;     /* LT_BG_*: how the epilogue reads the background image */
+    const uint16_t *block_owner; /* NULL: row block b belongs to partition b % n_parts (block-cyclic).  Else a HOST
+                                array of n_blocks = ceil(height / row_block) entries, block_owner[b] in [0, n_parts):
+                                any assignment of row blocks to partitions (e.g. cost-weighted from the previous
+                                frame's step counts, sharding.balance_blocks).  A partition's local rows are its
+                                blocks in ascending order.  Read during the call only. */
+    int32_t n_blocks;        /* entries of block_owner (checked against the frame) */
+    int32_t reserved;
 } lt_opts;
 
 /* background sampling of the epilogue kernel (same texels, bit-identical images) */

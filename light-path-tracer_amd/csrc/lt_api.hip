@@ -88,6 +88,8 @@ struct StreamSlot {
     hipStream_t stream = nullptr;
     Grow ws;     // ray records of lt_render_dev / the batch twins
     Grow dev;    // lt_render / batch twins: device-side inputs and outputs
+    Grow blocks; // block-owner table mode: this partition's block list on the device
+    std::vector<int32_t> blocks_host; // what `blocks` holds (skip the upload when unchanged)
     EventQuad own{}; // lt_render's private timing events (created on first use)
     bool own_ok = false;
 };
@@ -217,6 +219,7 @@ extern "C" int lt_release_stream(void *stream)
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     release(found->ws);
     release(found->dev);
+    release(found->blocks);
     if (found->own_ok) for (auto &e : found->own.e) (void)hipEventDestroy(e);
     delete found;
     return LT_OK;
@@ -234,7 +237,7 @@ extern "C" int lt_shutdown(void)
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (StreamSlot *sl : c.slots) {
-            release(sl->ws); release(sl->dev);
+            release(sl->ws); release(sl->dev); release(sl->blocks);
             if (sl->own_ok) for (auto &e : sl->own.e) (void)hipEventDestroy(e);
             delete sl;
         }
@@ -318,6 +321,26 @@ extern "C" int64_t lt_global_row(int64_t local_row, int32_t row_block, int32_t n
 {
     int64_t b = local_row / row_block, o = local_row - b * row_block;
     return (b * n_parts + part) * row_block + o;
+}
+
+// Row blocks partition `o.part` owns (ascending) and how many rows that is.  Block-cyclic unless a table is given.
+static int partition_blocks(int32_t height, const lt_opts &o, std::vector<int32_t> *blocks, int64_t *rows)
+{
+    const int64_t nb = (height + (int64_t)o.row_block - 1) / o.row_block;
+    if (o.block_owner && o.n_blocks != nb)
+        return fail(LT_ERR_INVALID_ARG, "block_owner has %d entries, the frame has %lld row blocks of %d rows", o.n_blocks,
+                    (long long)nb, o.row_block);
+    *rows = 0;
+    if (blocks) blocks->clear();
+    for (int64_t b = 0; b < nb; ++b) {
+        int owner = o.block_owner ? (int)o.block_owner[b] : (int)(b % o.n_parts);
+        if (o.block_owner && owner >= o.n_parts) return fail(LT_ERR_INVALID_ARG, "block_owner[%lld] = %d, n_parts = %d", (long long)b, owner, o.n_parts);
+        if (owner != o.part) continue;
+        int64_t r0 = b * o.row_block, r1 = r0 + o.row_block;
+        *rows += (r1 < height ? r1 : height) - r0;
+        if (blocks) blocks->push_back((int32_t)b);
+    }
+    return LT_OK;
 }
 
 static int make_metric(const lt_metric *m, double r_obs, double theta_obs, double h_schw, MetricConsts *mc)
@@ -571,6 +594,7 @@ static int check_opts(const lt_metric *metric, lt_opts *o)
     if (o->row_block <= 0) o->row_block = 16;
     if (o->n_parts <= 0) o->n_parts = 1;
     if (o->part < 0 || o->part >= o->n_parts) return fail(LT_ERR_INVALID_ARG, "part %d not in [0, %d)", o->part, o->n_parts);
+    if (o->block_owner && o->n_blocks <= 0) return fail(LT_ERR_INVALID_ARG, "block_owner given with n_blocks = %d", o->n_blocks);
     return LT_OK;
 }
 
@@ -593,7 +617,23 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     memset(&c, 0, sizeof(c));
     c.W = cam->width; c.H = cam->height;
     c.row_block = o.row_block; c.n_parts = o.n_parts; c.part = o.part;
-    c.rows_local = (int)lt_local_rows(c.H, c.row_block, c.n_parts, c.part);
+    hipStream_t s = (hipStream_t)o.stream;
+    std::vector<int32_t> owned;
+    int64_t rows_owned = 0;
+    if ((rc = partition_blocks(c.H, o, &owned, &rows_owned))) return rc;
+    c.rows_local = (int)rows_owned;
+    c.block_list = nullptr;
+    if (o.block_owner && !owned.empty()) { // the partition's block list goes to the device (once: re-uploaded only when it changes)
+        StreamSlot *sl;
+        if ((rc = get_slot(s, &sl))) return rc;
+        if (sl->blocks_host != owned || !sl->blocks.p) {
+            if ((rc = grow(sl->blocks, owned.size() * sizeof(int32_t), s))) return rc;
+            HIP_TRY(hipStreamSynchronize(s)); // frames in flight on this stream still read the old list
+            HIP_TRY(hipMemcpy(sl->blocks.p, owned.data(), owned.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            sl->blocks_host = owned;
+        }
+        c.block_list = (const int32_t *)sl->blocks.p;
+    }
     c.loop_around = o.loop_around;
     c.half_W = c.W / 2.0; c.half_H = c.H / 2.0;
     c.fx = (c.W / 2.0) / tan(cam->hfov / 2); // image_lens.py:138-139
@@ -610,7 +650,7 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     // top/bottom symmetry exactly when the reference applies it (image_lens.py:218-220)
     c.use_tb = o.tb_symmetry && metric->kind == LT_METRIC_KERR &&
                fabs(cam->theta_obs - M_PI / 2) <= 1e-8 + 1e-5 * (M_PI / 2) && fabs(cam->psi_y) <= 1e-8;
-    if (c.use_tb && o.n_parts != 1) return fail(LT_ERR_UNSUPPORTED, "tb_symmetry needs n_parts == 1");
+    if (c.use_tb && (o.n_parts != 1 || o.block_owner)) return fail(LT_ERR_UNSUPPORTED, "tb_symmetry needs n_parts == 1 and no block_owner table");
     c.trace_rows = c.use_tb ? (c.H + 1) / 2 : c.rows_local;
     c.tiles_x = (c.W + 7) / 8;
     if (c.rows_local <= 0) return LT_OK; // a partition may own no rows
@@ -642,6 +682,16 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
                 c.hot_x1 = clampi(ceil((bx + rx) / 8.0), 0, c.tiles_x);
                 // rows: global pixel rows -> this partition's local rows (block-cyclic: about 1/n_parts of them)
                 double ly0 = (by - ry) / o.n_parts - o.row_block, ly1 = (by + ry) / o.n_parts + o.row_block;
+                if (o.block_owner) { // any assignment: local rows of the first / last owned block that touches the band
+                    ly0 = 1e18; ly1 = -1.0;
+                    for (size_t i = 0; i < owned.size(); ++i) {
+                        double g0 = (double)owned[i] * o.row_block, g1 = g0 + o.row_block;
+                        if (g1 < by - ry || g0 > by + ry) continue;
+                        if ((double)i * o.row_block < ly0) ly0 = (double)i * o.row_block;
+                        ly1 = (double)(i + 1) * o.row_block;
+                    }
+                    if (ly1 < 0) ly0 = ly1 = 0.0;
+                }
                 c.hot_y0 = clampi(floor(ly0 / 8.0), 0, tiles_y);
                 c.hot_y1 = clampi(ceil(ly1 / 8.0), 0, tiles_y);
                 if (c.hot_x1 <= c.hot_x0 || c.hot_y1 <= c.hot_y0) c.hot_x0 = c.hot_x1 = c.hot_y0 = c.hot_y1 = 0;
@@ -661,7 +711,6 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     int64_t n_q = (int64_t)c.tiles_x * tiles_y * 64;
     double lambda_max = fmax(5000.0, 6.0 * cam->r_obs); // metrics.py:1132
 
-    hipStream_t s = (hipStream_t)o.stream;
     size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);
     Workspace w;
     if ((rc = get_workspace(s, (size_t)n_q, elem, &w))) return rc;
@@ -757,8 +806,9 @@ extern "C" int lt_render(const lt_camera *cam, const lt_metric *metric, const lt
     if (!cam || !metric || !opts) return fail(LT_ERR_INVALID_ARG, "null camera / metric / opts");
     lt_opts o = *opts;
     if ((rc = check_opts(metric, &o))) return rc;
-    int64_t rows = lt_local_rows(cam->height, o.row_block, o.n_parts, o.part);
-    if (rows < 0 || cam->width <= 0) return fail(LT_ERR_INVALID_ARG, "bad frame / partition");
+    if (cam->height <= 0 || cam->width <= 0) return fail(LT_ERR_INVALID_ARG, "bad frame / partition");
+    int64_t rows = 0;
+    if ((rc = partition_blocks(cam->height, o, nullptr, &rows))) return rc;
     if (bg && bg_channels != 1 && bg_channels != 3) return fail(LT_ERR_INVALID_ARG, "bg_channels must be 1 or 3");
     size_t n = (size_t)rows * cam->width;
     size_t n_full = (size_t)cam->height * cam->width;
@@ -878,6 +928,7 @@ extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, co
         }
         lt_opts op = o;
         op.n_parts = n_gpus; op.part = p; op.stream = (void *)P.s; op.timing = 0;
+        op.block_owner = nullptr; op.n_blocks = 0; // lt_render_multi partitions block-cyclically
         rc = render_dev_impl(cam, metric, &op, (const float *)at(bg != nullptr, o_bg), bg_channels, (float *)at(out_fa, P.o_fa),
                              (uint16_t *)at(out_w, P.o_w), (int8_t *)at(out_status, P.o_st), (uint32_t *)at(out_steps, P.o_steps),
                              (float *)at(out_rgb, P.o_rgb), (uint8_t *)at(out_rgba, P.o_rgba), (uint64_t *)(base + P.o_stats),

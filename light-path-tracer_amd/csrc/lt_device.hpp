@@ -243,8 +243,11 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     T r = r_in;
     if (__builtin_expect(any_inside, 0)) r = inside ? k.r_cut : r_in;
     T s2 = M<T>::sin2_floor(s);
-    T r2 = r * r;
-    T ra = r2 + k.a2;
+    // (explicit fma, not r * r + a2 / L * is2 - a below: under -ffp-contract=fast the compiler decides per template
+    // instantiation whether to fuse such an expression, and the checked and the branch-free variant of this function
+    // must round identically -- found in round 2 when a variant that let unflagged lanes keep the checked step's
+    // result differed from the other schedule in 41 of 4.2 M pixels by one ulp)
+    T ra = M<T>::fma(r, r, k.a2);
     T Sigma = M<T>::fma(-k.a2, s2, ra);          // r^2 + a^2 cos^2 as r^2 + a^2 - a^2 sin^2 (the 1e-15 floor is far below an ulp)
     T Delta = M<T>::fma(-k.two_M, r, ra);
     T SD = Sigma * Delta;
@@ -253,14 +256,14 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     T iD = (Sigma * s2) * t;
     T is2 = SD * t;
     if (__builtin_expect(any_inside, 0)) iS = inside ? T(0) : iS;
-    T P = r2 + rc.c_P;
+    T P = M<T>::fma(r, r, rc.c_P);
     T q = P * iD;
     T Lis2 = rc.L * is2;
     T pr2 = pr * pr;
     T iSpr = iS * pr;
     dr = Delta * iSpr;
     dth = pth * iS;
-    dph = iS * M<T>::fma(k.a, q, Lis2 - k.a);
+    dph = iS * M<T>::fma(k.a, q, M<T>::fma(rc.L, is2, -k.a));
     // (dropping the 2H terms -- zero on a null geodesic -- would save instructions, but the reference's RK4
     // solution drifts off-shell at h = 1 and they matter: measured median |d final_alpha| 5.6e-6 without them
     // against 4.4e-7 with them, and p99 1e-1 against 2e-5)

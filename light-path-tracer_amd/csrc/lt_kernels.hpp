@@ -36,6 +36,7 @@ struct CamConsts {
     int hot_x0, hot_x1, hot_y0, hot_y1; // tile rectangle queued next (bounds the critical curve), in columns
                                         // compacted by the strip; may be empty
     int row_block, n_parts, part;
+    const int32_t *block_list; // device: the row blocks this partition owns, ascending (NULL: block-cyclic b * n_parts + part)
     int loop_around;
     double half_W, half_H, fx, fy; // x_cam = (ix - W/2) / fx  (image_lens.py:141-142)
     double d[3], ex[3], ey[3];     // _psi_frame, image_lens.py:38-61
@@ -59,7 +60,8 @@ struct MetricConsts { // float64 view of the metric for K1 / K3
 __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
 {
     int b = lrow / c.row_block, o = lrow - b * c.row_block;
-    return (b * c.n_parts + c.part) * c.row_block + o;
+    int gb = c.block_list ? c.block_list[b] : b * c.n_parts + c.part;
+    return gb * c.row_block + o;
 }
 
 // Queue order of the tiles, so that the slowest rays START FIRST instead of forming the tail of the

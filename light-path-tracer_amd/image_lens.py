@@ -347,7 +347,7 @@ def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_f
         out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=mirror, want=("rgb", "rgba"), gpus=gpus)
         timings["render"] = perf_counter() - t0
         timings["gpu_integrate_ms"] = out["stats"]["integrate_ms"]
-        lensed, total, traced = out["rgb"], out["stats"]["rays"], out["stats"]["rays"]
+        lensed, total, traced = out["rgb"], height * width, out["stats"]["rays"]   # mirrored rows are copies, not rays
         rgba8 = out["rgba"] if lensed.ndim == 3 else None
 
     t0 = perf_counter()

@@ -48,7 +48,8 @@ class Opts(C.Structure):
                 ("tb_symmetry", C.c_int32), ("loop_around", C.c_int32), ("row_block", C.c_int32),
                 ("n_parts", C.c_int32), ("part", C.c_int32),
                 ("axis_refine_frac", C.c_double), ("phi_max", C.c_double), ("h_max", C.c_double),
-                ("stream", C.c_void_p), ("timing", C.c_int32), ("bg_sampling", C.c_int32)]
+                ("stream", C.c_void_p), ("timing", C.c_int32), ("bg_sampling", C.c_int32),
+                ("block_owner", C.c_void_p), ("n_blocks", C.c_int32), ("reserved", C.c_int32)]
 
 
 BG_LDS_TILES, BG_GLOBAL = 0, 1
@@ -154,8 +155,28 @@ def default_opts(**kw):
             v = INTEGRATORS[v]
         if k == "schedule" and isinstance(v, str):
             v = SCHEDULES[v]
+        if k == "block_owner":
+            set_block_owner(o, v)
+            continue
         setattr(o, k, v)
     return o
+
+
+def set_block_owner(opts, owner):
+    """Attach a row-block -> partition table (uint16, one entry per row block) to opts; None = block-cyclic."""
+    if owner is None:
+        opts.block_owner, opts.n_blocks, opts._owner_keep = None, 0, None
+        return
+    tab = np.ascontiguousarray(owner, dtype=np.uint16)
+    opts._owner_keep = tab                       # the struct only holds the address
+    opts.block_owner, opts.n_blocks = tab.ctypes.data, tab.size
+
+
+def owned_rows(height, row_block, owner, part):
+    """Global row index of every local row of partition `part` under a block-owner table (ascending)."""
+    owner = np.asarray(owner)
+    rows = [np.arange(b * row_block, min((b + 1) * row_block, height)) for b in np.nonzero(owner == part)[0]]
+    return np.concatenate(rows).astype(np.int64) if rows else np.zeros(0, dtype=np.int64)
 
 
 def _np_ptr(a):
@@ -308,7 +329,10 @@ def _background(cam, background):
 
 def render(cam, metric, opts, background=None, want=("fa", "winding", "status", "steps", "rgb", "rgba")):
     """Host-pointer frame render (lt_render).  Returns dict of numpy arrays (pinned memory) + 'stats'."""
-    rows = local_rows(cam.height, opts.row_block or 16, opts.n_parts or 1, opts.part)
+    if opts.block_owner:
+        rows = len(owned_rows(cam.height, opts.row_block or 16, opts._owner_keep, opts.part))
+    else:
+        rows = local_rows(cam.height, opts.row_block or 16, opts.n_parts or 1, opts.part)
     if rows < 0 or cam.width <= 0:
         raise LtraceError(ERR_INVALID_ARG, f"bad frame {cam.width}x{cam.height} or partition {opts.part}/{opts.n_parts}")
     bg, nch, gray = _background(cam, background)

@@ -756,3 +756,40 @@ def test_batch_dp45_exact_controller_reproduces_reference_step_sequences(name):
     esc = same_class & (st == 1)
     d = np.abs(fa[esc] - g["final_alpha"][esc])
     assert np.median(d) <= 1e-10 and np.quantile(d, 0.99) <= 1e-8 and d.max() <= 1e-5, (np.median(d), np.quantile(d, 0.99), d.max())
+
+
+def test_block_owner_table_partitions_reassemble_bit_identically():
+    """lt_opts.block_owner: ANY assignment of row blocks to partitions (here random, unbalanced, one partition empty; then
+    the cost-weighted table sharding.balance_blocks builds from the frame's own step counts) renders the same pixels
+    as the whole frame -- the rows just live elsewhere."""
+    import sharding
+    W, H, rb = 200, 250, 16                     # 16 row blocks, the last one short
+    cam = _cam(W, H, 50.0, psi=(0.01, 0.0))
+    met = ltrace.Metric(1, 0, 1.0, 0.9)
+    bg = _background(H, W, 4)
+    whole = ltrace.render(cam, met, ltrace.default_opts(precision=32), background=bg)
+    nb = -(-H // rb)
+    rng = np.random.default_rng(5)
+    tables = [(rng.integers(0, 3, nb).astype(np.uint16), 4)]          # partition 3 owns nothing
+    st = whole["steps"].astype(np.int64)
+    cost = np.array([st[b * rb:(b + 1) * rb].sum() for b in range(nb)])
+    chain = np.array([st[b * rb:(b + 1) * rb].max() for b in range(nb)])
+    tables.append((sharding.balance_blocks(cost, chain, 3, chain_cost=2000.0), 3))
+    for owner, n_parts in tables:
+        acc = {k: np.zeros_like(v) for k, v in whole.items() if k != "stats"}
+        rays = 0
+        for p in range(n_parts):
+            o = ltrace.default_opts(precision=32, n_parts=n_parts, part=p, row_block=rb, block_owner=owner)
+            part = ltrace.render(cam, met, o, background=bg)
+            rows = ltrace.owned_rows(H, rb, owner, p)
+            assert part["fa"].shape[0] == len(rows)
+            for k in acc:
+                acc[k][rows] = part[k]
+            rays += part["stats"]["rays"]
+        assert rays == W * H
+        for k in acc:
+            assert np.array_equal(acc[k], whole[k], equal_nan=True), k
+    with pytest.raises(ltrace.LtraceError):      # wrong table length
+        ltrace.render(cam, met, ltrace.default_opts(n_parts=2, block_owner=np.zeros(nb + 1, np.uint16)), want=("status",))
+    with pytest.raises(ltrace.LtraceError):      # owner out of range
+        ltrace.render(cam, met, ltrace.default_opts(n_parts=2, block_owner=np.full(nb, 2, np.uint16)), want=("status",))

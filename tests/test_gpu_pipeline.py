@@ -118,6 +118,7 @@ def test_cli_main_runs_end_to_end(tmp_path, capsys):
     text = capsys.readouterr().out
     assert img.shape == (64, 96, 3) and out.exists()
     assert "Metric: Kerr (M=1.0, a=0.9)" in text and "Benchmark summary" in text and "total rays: 6,144" in text
+    assert "traced rays: 3,072" in text          # the reference's top-half trace + mirror is the default (image_lens.py:218-220)
     # the fused path writes the GPU's RGBA8 with its own PNG encoder: same pixels as the reference's imsave call
     import matplotlib.image as mpimg
     ref_png = tmp_path / "imsave.png"

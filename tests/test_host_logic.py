@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     # sizes the C compiler gives for the structs in ltrace.h (x86-64 SysV)
     assert ctypes.sizeof(ltrace.Camera) == 8 + 6 * 8
     assert ctypes.sizeof(ltrace.Metric) == 8 + 2 * 8
-    assert ctypes.sizeof(ltrace.Opts) == 8 * 4 + 3 * 8 + 8 + 8
+    assert ctypes.sizeof(ltrace.Opts) == 8 * 4 + 3 * 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(ltrace.Stats) == 16 * 8 + 3 * 8
 
 

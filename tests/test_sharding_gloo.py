@@ -30,7 +30,7 @@ def _pixel_value(rows, width, channels):
     return ((r * 131 + x * 7 + ch * 3) % 251).to(torch.uint8)
 
 
-def _worker(rank, world, port, height, width, row_block, out_path):
+def _worker(rank, world, port, height, width, row_block, out_path, owner=None):
     for p in (ROOT, os.path.join(ROOT, "light-path-tracer_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -38,8 +38,9 @@ def _worker(rank, world, port, height, width, row_block, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        fg = sharding.FrameGather(height, width, 4, torch.uint8, "cpu", row_block, world, rank)
-        rows = sharding.global_row_index(height, row_block, world, rank)
+        fg = sharding.FrameGather(height, width, 4, torch.uint8, "cpu", row_block, world, rank, owner=owner)
+        rows = (sharding.global_row_index(height, row_block, world, rank) if owner is None
+                else torch.from_numpy(ltrace.owned_rows(height, row_block, owner, rank)))
         assert fg.local_view().shape[0] == rows.numel()
         fg.local_view().copy_(_pixel_value(rows, width, 4))      # "render" this rank's rows
         for _ in range(2):                                        # buffers are reusable across frames
@@ -69,3 +70,30 @@ def test_partition_covers_every_row_once():
     # the benchmark frame splits evenly at 1, 2, 4, 8 ranks
     for w in (1, 2, 4, 8):
         assert {ltrace.local_rows(4096, 16, w, r) for r in range(w)} == {4096 // w}
+
+
+def test_two_rank_gather_with_a_block_owner_table(tmp_path):
+    """The cost-weighted partition (lt_opts.block_owner / sharding.balance_blocks) through the same gather."""
+    height, width, rb = 70, 12, 8
+    owner = np.array([1, 1, 0, 1, 0, 0, 0, 1, 1], dtype=np.uint16)       # 9 blocks, the last one short
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(2, _free_port(), height, width, rb, out, owner), nprocs=2, join=True)
+    assert os.path.exists(out)
+
+
+def test_balance_blocks_properties():
+    rng = np.random.default_rng(0)
+    nb = 256
+    cost = rng.integers(9_000_000, 11_000_000, nb).astype(float)
+    chain = rng.integers(200, 400, nb).astype(float)
+    chain[[5, 77, 130, 200]] = [7484, 7329, 7111, 6822]
+    for world in (1, 2, 4, 8):
+        o = sharding.balance_blocks(cost, chain, world, chain_cost=137500.0)
+        assert o.dtype == np.uint16 and o.shape == (nb,) and o.max() < world
+        assert np.array_equal(o, sharding.balance_blocks(cost, chain, world, chain_cost=137500.0))   # deterministic
+        if world == 8:
+            # the four long chains land on four different ranks, and those ranks get less of the bulk
+            owners = o[[5, 77, 130, 200]]
+            assert len(set(owners.tolist())) == 4
+            bulk = np.array([cost[o == r].sum() for r in range(world)])
+            assert bulk[owners].max() < bulk[[r for r in range(world) if r not in owners]].min()

@@ -26,6 +26,9 @@ if [ "${1:-}" = measure ]; then
     bash tools/pipeline_bench.sh > $G/pipeline.txt 2>&1
     python3 tools/part_bench.py 4096 rk4 > $G/part_bench_rk4.log 2>&1
     python3 tools/part_bench.py 4096 dp45 > $G/part_bench_dp45.log 2>&1
+    python3 tools/balance_bench.py 4096 > $G/balance_bench.log 2>&1
+    for p in 25 205 50 75 0; do python3 bench.py --size 4096 --no-cpu-baseline --no-extras --steps 10 --emulate-parts 256 --emulate-part $p 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('row block $p alone (16 rows x 4096): integrate', d['roofline']['avg_launch_ms'], 'ms')"; done > $G/single_blocks.log 2>&1
     python3 tools/long_ray_pace.py > $G/long_ray_pace.log 2>&1
     python3 tools/long_ray_pace.py 2048 > $G/long_ray_pace_2048.log 2>&1
     python3 tools/lone_step.py > $G/lone.log 2>&1
@@ -60,7 +63,9 @@ elif [ "${1:-}" = collect ]; then
       echo "# tools/long_ray_pace.py 2048: the same for the 2048x2048 frame (config 3)"; grep -v amdgpu $G/long_ray_pace_2048.log
       echo "# tools/lone_step.py: bare RK4 step (lt_rk4_step_probe, probe build), cycles per wave-step by resident waves per SIMD"; grep -v amdgpu $G/lone.log
       echo "# tools/part_bench.py 4096 rk4: one rank of an N-GPU run under benchmark conditions"; grep n_parts $G/part_bench_rk4.log
-      echo "# tools/part_bench.py 4096 dp45 (float64)"; grep n_parts $G/part_bench_dp45.log; } > $P/${R}_long_ray_chain.txt
+      echo "# tools/part_bench.py 4096 dp45 (float64)"; grep n_parts $G/part_bench_dp45.log
+      echo "# single 16-row blocks rendered alone (bench.py --emulate-parts 256 --emulate-part b): blocks 25, 205, 50, 75 hold the four longest rays, block 0 none"; cat $G/single_blocks.log
+      echo "# tools/balance_bench.py 4096: cost-weighted row-block assignment (sharding.balance_blocks, lt_opts.block_owner) against block-cyclic, every rank emulated on one GPU"; grep -v amdgpu $G/balance_bench.log; } > $P/${R}_long_ray_chain.txt
     { echo "# $R: host-pointer lt_render, 4096x4096, RGBA8 destination only (tools/e2e_frame.py): what python image_lens.py pays per frame"
       grep -v amdgpu $G/e2e_frame.log; } > $P/${R}_end_to_end_frame.txt
     { echo "# $R: rocprofv3 --pmc VALUBusy (derived metric) over bench.py --steps 3 (tools/pmc_once.sh valubusy VALUBusy)"
