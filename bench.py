@@ -338,7 +338,7 @@ def main(argv=None):
     owner = None
     if args.owner_file:
         owner = np.load(args.owner_file).astype(np.uint16)
-    elif args.balance == "cost" and n_parts > 1 and args.metric == "kerr":
+    elif args.balance == "cost" and world > 1 and args.metric == "kerr":     # (an emulated rank takes --owner-file)
         # one untimed frame on the default partition: per-row-block step totals and longest ray, all-gathered; every rank
         # then computes the same owner table
         nb = (size + rb - 1) // rb
