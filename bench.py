@@ -468,25 +468,28 @@ def main(argv=None):
     # second region, same K and W, frames pipelined 3 deep (every rank takes part: the gather is collective)
     pipelined = None
     if F == 1 and not args.no_extras and args.pipelined_extra > 1:
-        psets = make_sets(args.pipelined_extra)
-        for j in range(max(args.warmup, args.pipelined_extra)):
-            step(None, j, psets)
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(None, i, psets)
-        fence()
-        tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
-        ltrace.timing_collect()
-        pel = float(tp.item())
-        pipelined = {"frames_in_flight": args.pipelined_extra, "value": round(rays_per_frame / (pel / steps) / 1e6, 2), "unit": "Mrays/s",
-                     "ms_per_step": round(pel / steps * 1e3, 4),
-                     "what": f"the same {args.steps} frames after the same warm-up, frame i on stream i % {args.pipelined_extra} with its own buffers: "
-                             "the tail of a frame (a few lone wavefronts finishing its longest rays) overlaps the bulk of the next. "
-                             "Throughput of a frame SEQUENCE; `value` above is frames strictly one after the other"}
-        del psets
+        try:
+            psets = make_sets(args.pipelined_extra)
+            for j in range(max(args.warmup, args.pipelined_extra)):
+                step(None, j, psets)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(None, i, psets)
+            fence()
+            tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+            ltrace.timing_collect()
+            pel = float(tp.item())
+            pipelined = {"frames_in_flight": args.pipelined_extra, "value": round(rays_per_frame / (pel / steps) / 1e6, 2), "unit": "Mrays/s",
+                         "ms_per_step": round(pel / steps * 1e3, 4),
+                         "what": f"the same {args.steps} frames after the same warm-up, frame i on stream i % {args.pipelined_extra} with its own buffers: "
+                                 "the tail of a frame (a few lone wavefronts finishing its longest rays) overlaps the bulk of the next. "
+                                 "Throughput of a frame SEQUENCE; `value` above is frames strictly one after the other"}
+            del psets
+        except Exception as e:      # the headline line must not depend on the extra region
+            pipelined = {"error": f"{type(e).__name__}: {e}"}
 
     # untimed extras (rank 0, one GPU): longest-ray chain and the host-pointer end-to-end frame
     chain = e2e = None
