@@ -271,19 +271,20 @@ __global__ void __launch_bounds__(256) k_prologue_arrays(MetricConsts m, const d
     }
 }
 
-// Diagnostic wave stamps (off unless LT_STAMPS_FILE is set): {start, end} of the 100 MHz real-time
-// counter, HW_ID (CU / SE / SIMD), XCC_ID -- one record per wavefront, never read by any kernel.
+// Diagnostic wave stamps (off unless LT_STAMPS_FILE is set): start and duration in ticks of the 100 MHz real-time
+// counter, duration in shader-clock cycles (s_memtime: cycles / ticks = the clock this wave saw), XCC_ID and the
+// longest ray's step count -- one record per wavefront, never read by any kernel.
 __device__ __forceinline__ uint64_t wave_clock() { return __builtin_amdgcn_s_memrealtime(); }
-__device__ __forceinline__ void write_stamp(uint4 *stamps, int64_t wave, uint64_t t0, uint32_t steps)
+__device__ __forceinline__ void write_stamp(uint4 *stamps, int64_t wave, uint64_t t0, uint32_t steps, uint64_t c0)
 {
     uint32_t max_steps = steps;
     for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(max_steps, off, 64); max_steps = o > max_steps ? o : max_steps; }
     uint64_t t1 = wave_clock();
     if ((threadIdx.x & 63) == 0) {
-        uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
         uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20); // HW_REG_XCC_ID
         uint4 v;
-        v.x = (uint32_t)t0; v.y = (uint32_t)(t1 - t0); v.z = hw; v.w = (xcc & 0xf) | (max_steps << 4);
+        v.x = (uint32_t)t0; v.y = (uint32_t)(t1 - t0); v.z = (uint32_t)(__builtin_amdgcn_s_memtime() - c0);
+        v.w = (xcc & 0xf) | (max_steps << 4);
         stamps[wave] = v;
     }
 }
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
 {
     int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_q) return;
-    uint64_t t0 = stamps ? wave_clock() : 0;
+    uint64_t t0 = stamps ? wave_clock() : 0, c0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
     WaveMeter meter;
     meter.begin(kstats, q >> 6);
     KerrConsts<T> k = k_in;
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
     uint32_t steps = st.steps;
     store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
     meter.end(kstats, wave_iters);
-    if (stamps) write_stamp(stamps, q >> 6, t0, steps);
+    if (stamps) write_stamp(stamps, q >> 6, t0, steps, c0);
 }
 
 // Queue schedule: persistent wavefronts.  The grid is sized to fill the chip once (blocks = CUs x
@@ -396,7 +397,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
                                                         uint32_t refill_min, uint32_t long_steps,
                                                         uint4 *__restrict__ stamps, uint64_t *__restrict__ kstats)
 {
-    uint64_t t0 = stamps ? wave_clock() : 0;
+    uint64_t t0 = stamps ? wave_clock() : 0, c0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
     const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     WaveMeter meter;
     meter.begin(kstats, wave_id);
@@ -472,7 +473,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
         }
     }
     meter.end(kstats, wave_iters);
-    if (stamps) write_stamp(stamps, wave_id, t0, total_steps);
+    if (stamps) write_stamp(stamps, wave_id, t0, total_steps, c0);
 }
 
 template <typename T>

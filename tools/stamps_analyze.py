@@ -8,7 +8,7 @@ t0 = (t0 - t0.min()) & 0xffffffff
 t1 = t0 + dur
 steps = a[:, 3] >> 4
 xcc = a[:, 3] & 0xf
-hw = a[:, 2]
+cyc = a[:, 2].astype(np.int64)   # shader-clock cycles of the wave's lifetime (s_memtime)
 T = t1.max()
 print(f"waves {len(a)}  kernel span {T/100:.1f} us (100 MHz ticks)  mean wave dur {dur.mean()/100:.1f} us  max {dur.max()/100:.1f} us")
 print("ticks per step: median", np.median(dur / np.maximum(steps, 1)), " lone-ish (last 1% finishing)", np.median((dur / np.maximum(steps, 1))[np.argsort(t1)[-len(a)//100:]]))
@@ -21,10 +21,7 @@ for i in range(20):
     print(f"  t={lo/100:8.1f}-{hi/100:8.1f} us  resident waves {ov:8.1f}  ({ov/1024:.2f}/SIMD)  started {started}")
 order = np.argsort(-dur)[:8]
 for i in order:
-    print(f"  long wave {i}: start {t0[i]/100:.1f} us dur {dur[i]/100:.1f} us steps {steps[i]} ticks/step {dur[i]/max(steps[i],1):.2f} xcc {xcc[i]}")
+    print(f"  long wave {i}: start {t0[i]/100:.1f} us dur {dur[i]/100:.1f} us steps {steps[i]} us/step {dur[i]/100/max(steps[i],1):.4f} "
+          f"cycles/step {cyc[i]/max(steps[i],1):.0f} clock {cyc[i]/max(dur[i],1)*100:.0f} MHz xcc {xcc[i]}")
 print("waves per xcc:", np.bincount(xcc, minlength=8))
-# where the longest waves ran: HW_ID fields (gfx9 layout: wave [3:0], simd [5:4], cu [11:8], sh [12], se [15:13])
-print("placement of the longest waves (xcc, se, sh, cu, simd, slot):")
-for i in order:
-    h = int(hw[i])
-    print(f"  wave {i}: xcc {xcc[i]} se {(h >> 13) & 7} sh {(h >> 12) & 1} cu {(h >> 8) & 15} simd {(h >> 4) & 3} slot {h & 15}  steps {steps[i]}")
+print(f"clock seen by waves: median {np.median(cyc / np.maximum(dur, 1)) * 100:.0f} MHz, lifetime-weighted {cyc.sum() / max(dur.sum(), 1) * 100:.0f} MHz")
