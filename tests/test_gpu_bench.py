@@ -1,0 +1,59 @@
+"""bench.py on the GPU box, as the driver runs it (a subprocess: torch is imported before the library there):
+the JSON contract, the executed-work roofline (frac <= 1 by construction), the extras."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_north_star_line_has_the_contract_fields_and_an_honest_roofline():
+    d = _bench(["--steps", "3", "--warmup", "1", "--cpu-seconds", "2"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["dtype"] == "f32"
+    assert d["config"]["workload"] == "kerr_a0.9_shadow_4096x4096_r50_rk4" and d["config"]["rays_per_frame"] == 4096 * 4096
+    assert d["vs_baseline"] is None and d["scaling"] == "strong" and d["higher_is_better"] is True
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / d["ms_per_step"] / 1e3) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["peak"] == 157.3 and r["unit"] == "TFLOP/s" and r["bound"] == "valu_issue_fp32"
+    assert r["executed"]["wave_iters_per_launch"] > 4e7 and 1500 < r["executed"].get("clock_mhz_held", 2000) < 2600
+    if r["frac"] is not None:                       # a VALU count for this workload is committed under profiles/
+        assert 0.5 < r["frac"] <= 1.0 and abs(r["achieved"] / r["peak"] - r["frac"]) < 2e-3
+        assert r["frac"] <= r["executed"]["frac_at_held_clock"] <= 1.0
+        assert r["avg_launch_ms"] + r["other_kernels_ms"]["prologue"] + r["other_kernels_ms"]["epilogue"] <= d["ms_per_step"] * 1.02
+    if r["traffic"] is not None:                    # only printed when the profile's build id is the library's
+        assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.2
+    assert r["algorithmic_as_written"]["flops_per_launch"] > 2e12
+    assert d["pipelined"]["frames_in_flight"] == 3 and d["pipelined"]["value"] > 0.9 * d["value"]
+    assert d["chain_floor"]["longest_ray_steps"] > 2000 and d["chain_floor"]["alone_ms"] < r["avg_launch_ms"]
+    assert 5.0 < d["end_to_end_ms"]["pinned_dst_ms"] < 40.0
+    assert d["cpu_baseline"]["unit"] == "Mrays/s" and d["cpu_baseline"]["cores"] >= 1 and "perf build" in d["cpu_baseline"]["kind"]
+    assert d["ranks"]["rccl_world"] == 1
+
+
+def test_other_workloads_and_flags():
+    d = _bench(["--size", "1024", "--metric", "schwarzschild", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["config"]["workload"].startswith("schwarzschild_a0.0_shadow_1024x1024") and d["roofline"]["frac"] is None
+    d = _bench(["--size", "1024", "--r-obs", "100", "--background", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert d["config"]["workload"].endswith("_lensed_background") and d["config"]["bg_sampling"] == "global" and "pipelined" not in d
+    d = _bench(["--size", "1024", "--frames-in-flight", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["config"]["frames_in_flight"] == 2
+    d = _bench(["--size", "1024", "--emulate-parts", "4", "--emulate-part", "3", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline", "--no-extras"])
+    assert d["config"]["rays_per_frame"] == 1024 * 256 and "emulated rank 3" in d["config"]["row_partition"]
