@@ -23,6 +23,10 @@ namespace lt {
 // reads the compare's lane mask directly (HIP's __ballot(int) first materialises the bool in a VGPR and
 // compares it again: two extra VALU instructions per test).
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// true if the predicate holds in every ACTIVE lane.  (Written on the predicate itself, not as !wave_any(!p): when p is
+// also used for per-lane selects the compiler keeps its lane mask, and negating it first costs a 0/1 materialisation
+// and a compare -- two VALU instructions per test.)
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
 
 
 // ---------------------------------------------------------------------------------------
@@ -435,14 +439,18 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
     uint32_t done = 0;
     // One attempt: from state `from` at affine parameter lam into `to`; true if it was an ordinary far-field step.
     // (predicates are combined with & and |, not && and ||: short-circuit evaluation would turn them into branches)
+    // The streak only takes FULL base steps: h = h_base needs remaining >= h_base, i.e. lam <= lambda_max - h_base
+    // (the tracer's h = min(h_base, remaining) is then h_base exactly).  A ray within one base step of the range end
+    // fails the test and takes its last, shorter step in the general iteration.  With h invariant the step's h / 2 and
+    // h / 6, the subtraction and the min leave the loop.
+    const T lam_limit = k.lambda_max - rc.hb;
     auto attempt = [&](const State5<T> &from, T lam, State5<T> &to, T &h) -> bool {
-        T remaining = k.lambda_max - lam;
-        h = M<T>::min(rc.hb, remaining);
+        h = rc.hb;
         T min_r, max_d;
         to = kerr_rk4_step_fast(k, rc, from, h, min_r, max_d);
         T mag = M<T>::abs(to.r) + M<T>::abs(to.th) + M<T>::abs(to.ph) + M<T>::abs(to.pr) + M<T>::abs(to.pth);
         ++done;
-        return (remaining > T(0)) & M<T>::finite(mag) & (to.r >= k.rc4) & (to.r < k.r_escape) & (min_r > k.r_cut) &
+        return (lam <= lam_limit) & M<T>::finite(mag) & (to.r >= k.rc4) & (to.r < k.r_escape) & (min_r > k.r_cut) &
                !(max_d > T(0.25));
     };
     // The state ping-pongs between two register sets (A = s.y, B) so that accepting an attempt costs no copies:
@@ -452,7 +460,7 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
     T h;
     for (;;) {
         bool good = attempt(s.y, s.lam, b, h);
-        if (wave_any(!good) | (done >= max_steps)) {
+        if (!wave_all(good) | (done >= max_steps)) {
             s.y.r = good ? b.r : s.y.r; s.y.th = good ? b.th : s.y.th; s.y.ph = good ? b.ph : s.y.ph;
             s.y.pr = good ? b.pr : s.y.pr; s.y.pth = good ? b.pth : s.y.pth;
             s.lam = good ? s.lam + h : s.lam;
@@ -462,7 +470,7 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
         s.lam += h;
         ++s.steps;
         good = attempt(b, s.lam, s.y, h);
-        if (wave_any(!good) | (done >= max_steps)) {
+        if (!wave_all(good) | (done >= max_steps)) {
             s.y.r = good ? s.y.r : b.r; s.y.th = good ? s.y.th : b.th; s.y.ph = good ? s.y.ph : b.ph;
             s.y.pr = good ? s.y.pr : b.pr; s.y.pth = good ? s.y.pth : b.pth;
             s.lam = good ? s.lam + h : s.lam;
