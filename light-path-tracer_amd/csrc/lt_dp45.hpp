@@ -16,6 +16,7 @@ template <typename T> struct Rk4 {
     using State = RayState<T>;
     static constexpr int EVALS_FIXED = 0, EVALS_PER_STEP = 4;
     static constexpr int MIN_WAVES_PER_SIMD = 1; // no constraint: float32 fits 5, float64 2
+    static constexpr bool GHOST_LANES = true;    // fixed step: a few rays take ~20x the mean step count (k_kerr_direct)
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &, State &s, T p_r, T p_th)
     {
         ray_start(k, s, p_r, p_th);
@@ -69,6 +70,7 @@ template <typename T, bool EXACT_CTRL = false> struct Dp45 {
     // hold the register allocation at 256 (it sits just above); the float64 pow of the exact controller does not fit
     // there without spilling, so that variant runs one wave per SIMD
     static constexpr int MIN_WAVES_PER_SIMD = EXACT_CTRL ? 1 : 2;
+    static constexpr bool GHOST_LANES = false;   // adaptive steps: no ray is long enough to be alone on the chip
 
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, T p_r, T p_th)
     {

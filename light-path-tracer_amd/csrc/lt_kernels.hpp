@@ -336,7 +336,32 @@ __device__ __forceinline__ void store_fin(typename Vec4<T>::type *fin0, typename
     fin1[q] = v1;
 }
 
+// Lane `lane`'s copy of a register-resident struct, taken by the lanes for which `take` holds (one v_readlane and one
+// select per 32-bit word; `lane` is wave-uniform).
+template <typename S> __device__ __forceinline__ void take_from_lane(S &s, uint32_t lane, bool take)
+{
+    static_assert(sizeof(S) % 4 == 0, "whole 32-bit words");
+    constexpr int N = (int)(sizeof(S) / 4);
+    uint32_t w[N];
+    __builtin_memcpy(w, &s, sizeof(S));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)w[i], (int)lane);
+        w[i] = take ? v : w[i];
+    }
+    __builtin_memcpy(&s, w, sizeof(S));
+}
+
 // Direct schedule: one work-item per ray, a wavefront = one 8x8 tile.
+//
+// Ghost lanes (integrators with Integ::GHOST_LANES).  A wavefront still running after `long_iters` iterations hosts
+// one of the few very long rays; the launch cannot end before it does, and at the end of the launch that wave is alone
+// on its SIMD with one lane left.  Measured on MI355X (tools/scratch/lone_pace_by_lanes.py): a lone
+// wavefront with 40 or more of its 64 lanes enabled takes 0.557 us per RK4 step on every CU; with 32 or fewer enabled
+// the same instruction stream takes 0.557 to 0.75 us depending on the CU it landed on.  So a long wave does not let
+// its finished lanes idle: from `long_iters` on, a lane whose ray has ended stores its result and then shadows the
+// first lane that is still running (same state, same constants -- a bitwise twin, so every wave-level predicate is what
+// it would have been without it).  Ghosts never store; no output depends on them.
 template <typename T, typename Integ>
 __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
@@ -357,25 +382,61 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
     st.y.r = k.r_obs; st.y.th = k.theta_obs; st.y.ph = T(0); st.y.pr = rec.x; st.y.pth = rec.y;
     st.steps = 0;
     int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
-    uint32_t wave_iters = 0; // wave-uniform: loop iterations this wave issued (streak attempts + general iterations)
+    uint32_t wave_iters = 0; // loop iterations this wave issued (streak attempts + general iterations)
+    RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
     if (flags & FLAG_OK) {
-        RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
         Integ::start(k, rc, st, rec.x, rec.y);
-        // A wave still running after `long_iters` iterations hosts one of the few very long rays (the
-        // launch cannot end before they do): it raises its issue priority over the bulk waves sharing
-        // its SIMD.  The iteration counter is wave-uniform (SGPR), so the check costs no VALU.
+        // The iteration counter is uniform over the lanes still in the loop (SGPR), so the checks on it cost no VALU.
         uint32_t it = 0;
         bool raised = false;
         do {
             it += Integ::streak(k, rc, st, 64u);
             ev = Integ::advance(k, rc, st);
-            if (++it >= long_iters && !raised) { __builtin_amdgcn_s_setprio(3); raised = true; }
+            ++it;
+            if (Integ::GHOST_LANES) {
+                if (it >= long_iters) break;
+            } else if (it >= long_iters && !raised) {
+                // no ghost lanes for this integrator: the long wave only raises its issue priority over the bulk
+                // waves sharing its SIMD
+                __builtin_amdgcn_s_setprio(3);
+                raised = true;
+            }
         } while (ev == EV_RUNNING);
         // lanes leave the loop one by one; the last one out has counted every iteration the wave issued
         wave_iters = it;
     }
     uint32_t steps = st.steps;
-    store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
+    bool real = ev == EV_RUNNING; // only with ghost lanes: this lane's ray is still running
+    if (Integ::GHOST_LANES && wave_any(real)) {
+        __builtin_amdgcn_s_setprio(3);
+        if (!real) store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
+        uint32_t lead = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(real));
+        uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)wave_iters, (int)lead); // every running lane holds the same count
+        bool sync = true;
+        for (;;) {
+            if (sync) {
+                lead = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(real));
+                take_from_lane(st, lead, !real);
+                take_from_lane(rc, lead, !real);
+                sync = false;
+            }
+            it += Integ::streak(k, rc, st, 64u);
+            int e = Integ::advance(k, rc, st);
+            ++it;
+            if (wave_any(e != EV_RUNNING)) {
+                if (real & (e != EV_RUNNING)) {
+                    steps = st.steps;
+                    store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, e, steps);
+                    real = false;
+                }
+                if (!wave_any(real)) break;
+                sync = true; // a ghost whose twin ended, or a new ghost: shadow the first lane still running
+            }
+        }
+        wave_iters = it;
+    } else {
+        store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
+    }
     meter.end(kstats, wave_iters);
     if (stamps) write_stamp(stamps, q >> 6, t0, steps, c0);
 }
@@ -411,6 +472,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
     uint64_t q = 0;
     uint32_t total_steps = 0, wave_iters = 0;
     int prio = 0;
+    bool synced = false;        // wave-uniform: the ghost lanes shadow the current first live lane
     typename Integ::State st;
     RayConsts<T> rc = make_ray_consts(k, T(0), false);
     Integ::start(k, rc, st, T(0), T(0));
@@ -454,13 +516,25 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
             if (drained) break;
             continue;
         }
-        if (have) {
+        // Ghost lanes (see k_kerr_direct): once the queue has drained, a wave hosting a long ray keeps its idle lanes
+        // enabled as bitwise twins of its first live lane.  They never store and are re-synchronised whenever a
+        // lane's ray (or a ghost's twin) ends.
+        const bool ghosting = Integ::GHOST_LANES && drained && prio == 3;
+        if (ghosting && !synced) {
+            uint32_t lead = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(have));
+            take_from_lane(st, lead, !have);
+            take_from_lane(rc, lead, !have);
+            synced = true;
+        }
+        bool ended = false;
+        if (have | ghosting) {
             // a far-field streak only while nothing is waiting for it to end: every lane busy (fewer idle lanes than
             // the refill threshold) or the queue drained
             if (n_idle < refill_min || drained) wave_iters += Integ::streak(k, rc, st, 16u);
             int ev = Integ::advance(k, rc, st);
             ++wave_iters;
-            if (ev != EV_RUNNING) {
+            ended = ev != EV_RUNNING;
+            if (ended & have) {
                 store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rc.L, ev, st.steps);
                 total_steps += st.steps;
                 have = false;
@@ -470,7 +544,9 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_queue(K
         if (want != prio) {
             prio = want;
             if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            synced = false;
         }
+        if (ghosting && wave_any(ended)) synced = false;
     }
     meter.end(kstats, wave_iters);
     if (stamps) write_stamp(stamps, wave_id, t0, total_steps, c0);
