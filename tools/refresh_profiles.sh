@@ -32,6 +32,8 @@ import json,sys; d=json.loads(sys.stdin.readline()); print('row block $p alone (
     python3 tools/long_ray_pace.py > $G/long_ray_pace.log 2>&1
     python3 tools/long_ray_pace.py 2048 > $G/long_ray_pace_2048.log 2>&1
     python3 tools/lone_step.py > $G/lone.log 2>&1
+    LT_STAMPS_FILE=/tmp/lt_stamps_lanes.bin LT_D_LONG=2000000000 python3 tools/lone_pace_by_lanes.py > $G/lone_lanes_off.log 2>&1
+    LT_STAMPS_FILE=/tmp/lt_stamps_lanes.bin python3 tools/lone_pace_by_lanes.py > $G/lone_lanes_on.log 2>&1
     python3 tools/e2e_frame.py > $G/e2e_frame.log 2>&1
     bash tools/pmc_once.sh valubusy "VALUBusy" > $G/valubusy.log 2>&1
     echo chain done
@@ -62,6 +64,8 @@ elif [ "${1:-}" = collect ]; then
       echo "# tools/long_ray_pace.py: the longest rays of the frame, each traced ALONE on the chip (one wavefront)"; grep -v amdgpu $G/long_ray_pace.log
       echo "# tools/long_ray_pace.py 2048: the same for the 2048x2048 frame (config 3)"; grep -v amdgpu $G/long_ray_pace_2048.log
       echo "# tools/lone_step.py: bare RK4 step (lt_rk4_step_probe, probe build), cycles per wave-step by resident waves per SIMD"; grep -v amdgpu $G/lone.log
+      echo "# tools/lone_pace_by_lanes.py with LT_D_LONG=2000000000 (no wave ever uses ghost lanes): the pace of a lone wavefront by the number of its lanes still enabled"; grep -v amdgpu $G/lone_lanes_off.log
+      echo "# tools/lone_pace_by_lanes.py, defaults (ghost lanes after 1024 iterations)"; grep -v amdgpu $G/lone_lanes_on.log
       echo "# tools/part_bench.py 4096 rk4: one rank of an N-GPU run under benchmark conditions"; grep n_parts $G/part_bench_rk4.log
       echo "# tools/part_bench.py 4096 dp45 (float64)"; grep n_parts $G/part_bench_dp45.log
       echo "# single 16-row blocks rendered alone (bench.py --emulate-parts 256 --emulate-part b): blocks 25, 205, 50, 75 hold the four longest rays, block 0 none"; cat $G/single_blocks.log
