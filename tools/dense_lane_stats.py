@@ -19,3 +19,8 @@ print(f"one track per lane, 64 consecutive tracks per wave: utilisation bound su
 o = np.argsort(att)
 ws = att[o].reshape(-1, 64)
 print(f"same, tracks sorted by length first (what perfect grouping would give): {ws.sum() / (64 * ws.max(axis=1).sum()):.3f}")
+srt = np.sort(w, axis=1)[:, ::-1]          # per wave, longest first
+tot = srt[:, 0].sum()
+for live in (1, 2, 4, 8, 12, 16, 32):
+    # iterations of a wave during which at most `live` lanes are still running: from the (live+1)-th longest track's end to the longest's
+    print(f"share of wave iterations with <= {live:2d} live lanes: {(srt[:, 0] - srt[:, live]).sum() / tot:.3f}")
