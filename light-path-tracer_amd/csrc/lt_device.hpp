@@ -238,9 +238,21 @@ __device__ __forceinline__ RayConsts<T> make_ray_consts(const KerrConsts<T> &k, 
 //
 // CHECKED = false leaves the r <= r_cut handling out: for callers that know, or verify afterwards, that
 // the radius is outside (kerr_rk4_step_fast below).  Arithmetic otherwise identical.
+//
+// The three velocities are products -- dr = Delta (p_r / Sigma), dtheta = p_theta / Sigma, dphi = (1 / Sigma) u -- and the
+// last stage of an RK4 step adds them to a running sum: the compiler (-ffp-contract=fast) fuses that product and sum,
+// for the stage whose result has no other use.  kerr_rhs_parts hands out the factors so that the step can write that
+// fma itself (kerr_rk4_step_impl): the rounding then no longer depends on what a compiler decides to fuse, and the
+// packed form of the step (kerr_rk4_step_fast_pk) can be made to round identically.
+template <typename T> struct KerrRhsParts {
+    T Delta, iSpr; // dr = Delta * iSpr
+    T iS;          // dtheta = p_theta * iS
+    T u;           // dphi = iS * u
+    T dpr, dpth;
+};
+
 template <typename T, bool CHECKED = true>
-__device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T s, T c, T pr, T pth,
-                                            T &dr, T &dth, T &dph, T &dpr, T &dpth)
+__device__ __forceinline__ KerrRhsParts<T> kerr_rhs_parts(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T s, T c, T pr, T pth)
 {
     bool inside = CHECKED && r_in <= k.r_cut;
     const bool any_inside = CHECKED && wave_any(inside); // almost never: only a stage of the last steps before capture
@@ -264,10 +276,11 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     T q = P * iD;
     T Lis2 = rc.L * is2;
     T pr2 = pr * pr;
-    T iSpr = iS * pr;
-    dr = Delta * iSpr;
-    dth = pth * iS;
-    dph = iS * M<T>::fma(k.a, q, M<T>::fma(rc.L, is2, -k.a));
+    KerrRhsParts<T> o;
+    o.Delta = Delta;
+    o.iSpr = iS * pr;
+    o.iS = iS;
+    o.u = M<T>::fma(k.a, q, M<T>::fma(rc.L, is2, -k.a));
     // (dropping the 2H terms -- zero on a null geodesic -- would save instructions, but the reference's RK4
     // solution drifts off-shell at h = 1 and they matter: measured median |d final_alpha| 5.6e-6 without them
     // against 4.4e-7 with them, and p99 1e-1 against 2e-5)
@@ -277,9 +290,22 @@ __device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayCon
     // dp_r = -(F_r - 2H Sigma_r) / (2 Sigma) with F_r = (2r - 2M)(q^2 + p_r^2) - 4 r q, Sigma_r = 2r; the factor
     // 1/2 goes into the bracket:  -(1/Sigma) [ (r - M)(q^2 + p_r^2) - r (2q + 2H) ]
     T rt = r * M<T>::fma(T(2), q, H2);
-    dpr = -iS * M<T>::fma(r - k.M, M<T>::fma(q, q, pr2), -rt);
+    o.dpr = -iS * M<T>::fma(r - k.M, M<T>::fma(q, q, pr2), -rt);
     // dp_theta likewise: F_theta = 2 s c (a^2 - L^2/s^4), Sigma_theta = -2 a^2 s c:  -(1/Sigma) s c [a^2 (1 + 2H) - (L/s^2)^2]
-    dpth = -iS * ((s * c) * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2)));
+    o.dpth = -iS * ((s * c) * M<T>::fma(H2, k.a2, M<T>::fma(-Lis2, Lis2, k.a2)));
+    return o;
+}
+
+template <typename T, bool CHECKED = true>
+__device__ __forceinline__ void kerr_rhs_sc(const KerrConsts<T> &k, const RayConsts<T> &rc, T r_in, T s, T c, T pr, T pth,
+                                            T &dr, T &dth, T &dph, T &dpr, T &dpth)
+{
+    const KerrRhsParts<T> o = kerr_rhs_parts<T, CHECKED>(k, rc, r_in, s, c, pr, pth);
+    dr = o.Delta * o.iSpr;
+    dth = pth * o.iS;
+    dph = o.iS * o.u;
+    dpr = o.dpr;
+    dpth = o.dpth;
 }
 
 template <typename T>
@@ -353,7 +379,7 @@ __device__ __forceinline__ State5<T> kerr_rk4_step_impl(const KerrConsts<T> &k, 
     t_r = M<T>::fma(h, k_r, y.r); t_pr = M<T>::fma(h, k_pr, y.pr); t_pth = M<T>::fma(h, k_pth, y.pth);
     T d4 = h * k_th;
     sincos_shift<T, CHECKED>(y.th, s0, c0, d4, s, c);
-    kerr_rhs_sc<T, CHECKED>(k, rc, t_r, s, c, t_pr, t_pth, k_r, k_th, k_ph, k_pr, k_pth);
+    const KerrRhsParts<T> k4 = kerr_rhs_parts<T, CHECKED>(k, rc, t_r, s, c, t_pr, t_pth);
     if (!CHECKED) {
         // (a NaN stage value is ignored by min / max; it makes the step's result non-finite in either variant)
         min_r = M<T>::min(M<T>::min(r2, r3), t_r);
@@ -361,11 +387,12 @@ __device__ __forceinline__ State5<T> kerr_rk4_step_impl(const KerrConsts<T> &k, 
     }
     T h6 = h * T(1.0 / 6.0);
     State5<T> o;
-    o.r = M<T>::fma(h6, a_r + k_r, y.r);
-    o.th = M<T>::fma(h6, a_th + k_th, y.th);
-    o.ph = M<T>::fma(h6, a_ph + k_ph, y.ph);
-    o.pr = M<T>::fma(h6, a_pr + k_pr, y.pr);
-    o.pth = M<T>::fma(h6, a_pth + k_pth, y.pth);
+    // (k1 + 2 k2 + 2 k3) + k4 with the velocity products of the last stage fused into the sum, see kerr_rhs_parts
+    o.r = M<T>::fma(h6, M<T>::fma(k4.Delta, k4.iSpr, a_r), y.r);
+    o.th = M<T>::fma(h6, M<T>::fma(t_pth, k4.iS, a_th), y.th);
+    o.ph = M<T>::fma(h6, M<T>::fma(k4.iS, k4.u, a_ph), y.ph);
+    o.pr = M<T>::fma(h6, a_pr + k4.dpr, y.pr);
+    o.pth = M<T>::fma(h6, a_pth + k4.dpth, y.pth);
     return o;
 }
 
@@ -383,6 +410,142 @@ __device__ __forceinline__ State5<T> kerr_rk4_step_fast(const KerrConsts<T> &k, 
                                                         const State5<T> &y, T h, T &min_r, T &max_d)
 {
     return kerr_rk4_step_impl<T, false>(k, rc, y, h, min_r, max_d);
+}
+
+// ---------------------------------------------------------------------------------------
+// The same step for a wavefront that is ALONE on its SIMD (the last waves of a launch, hosting the few very long
+// rays; k_kerr_direct's ghost-lane phase).  Such a wave issues one instruction per ~4.8 cycles whatever the
+// instruction is (tools/issue_probe.py), and a packed v_pk_fma_f32 / v_pk_mul_f32 -- two float32 operations on a
+// 64-bit register pair, each half of each source chosen by op_sel -- costs it 5.3: wherever two operations of the
+// step take their operands from the same pairs they share one issue slot.  (With two or more waves per SIMD a
+// packed instruction costs two issue slots and this form gains nothing: the bulk keeps the scalar step.)
+// Every operation below is one of the scalar step's, with the same operands: a product x * y is written
+// fma(x, y, -0) where its slot-mate is an fma -- identical bits, including the sign of a zero product -- so the
+// result is bit-identical to kerr_rk4_step_fast (tests/test_gpu_ghost_lanes.py runs whole frames through either).
+// Pairs: [ps, pc] polynomials of the stage rotation, [s, c], [s^2, s c], [r^2 + a^2, P], [Sigma, Delta] s^2 -> [1/Delta, 1/Sigma]
+// after the one reciprocal, [L/s^2, .], [p_r/Sigma, dtheta], [dphi, 2H], [dp_r, dp_theta], and the RK4 bookkeeping of
+// the (r, theta) and (p_r, p_theta) components.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct PkStage {
+    float dr, dth, dph; // LAST: unset
+    f32x2 dp;           // [dp_r, dp_theta]
+    float Delta, iSpr, iS, u; // LAST only: the factors of dr, dtheta, dphi (KerrRhsParts)
+};
+
+__device__ __forceinline__ f32x2 pk_bc(float x) { return (f32x2){x, x}; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// right-hand side at (r, [sin, cos], [p_r, p_theta]); kerr_rhs_sc<float, false>, LAST: kerr_rhs_parts<float, false>
+template <bool LAST = false>
+__device__ __forceinline__ PkStage kerr_rhs_pk(const KerrConsts<float> &k, const RayConsts<float> &rc, float r, f32x2 sc, f32x2 p)
+{
+#pragma clang fp contract(off)
+    PkStage o;
+    const f32x2 s2sc = pk_fma(pk_bc(sc.x), sc, (f32x2){1e-15f, -0.0f});          // [s^2 + 1e-15, s c]
+    const float s2 = s2sc.x;
+    const f32x2 raP = pk_fma(pk_bc(r), pk_bc(r), (f32x2){k.a2, rc.c_P});        // [r^2 + a^2, P]
+    const float ra = raP.x, P = raP.y;
+    const float Sigma = __builtin_fmaf(-k.a2, s2, ra);
+    const float Delta = __builtin_fmaf(-k.two_M, r, ra);
+    const f32x2 SDs2 = (f32x2){Sigma, Delta} * pk_bc(s2);                       // [Sigma s^2, Delta s^2]
+    const float SD = Sigma * Delta;
+    const float t = M<float>::rcp_pos(SD * s2);
+    const f32x2 inv = SDs2 * pk_bc(t);                                          // [1/Delta, 1/Sigma]
+    const float iD = inv.x, iS = inv.y;
+    const float is2 = SD * t;
+    const f32x2 Lu = pk_fma(pk_bc(rc.L), pk_bc(is2), (f32x2){-0.0f, -k.a});     // [L / s^2, L / s^2 - a]
+    const float Lis2 = Lu.x;
+    const float q = P * iD;
+    const float pr2 = p.x * p.x;
+    const float u2 = __builtin_fmaf(k.a, q, Lu.y);
+    const float W = __builtin_fmaf(rc.L, Lis2, __builtin_fmaf(k.a2, s2, rc.c_W));
+    const float F = __builtin_fmaf(Delta, pr2, __builtin_fmaf(p.y, p.y, __builtin_fmaf(-P, q, W)));
+    float H2;
+    if (LAST) {
+        o.Delta = Delta; o.iSpr = iS * p.x; o.iS = iS; o.u = u2;
+        H2 = F * iS;
+    } else {
+        const f32x2 ip = pk_bc(iS) * p;                                         // [p_r / Sigma, p_theta / Sigma]
+        o.dr = Delta * ip.x;
+        o.dth = ip.y;
+        const f32x2 dphH = pk_bc(iS) * (f32x2){u2, F};                          // [dphi, 2H]
+        o.dph = dphH.x;
+        H2 = dphH.y;
+    }
+    const float rt = r * __builtin_fmaf(2.0f, q, H2);
+    const float b = __builtin_fmaf(r - k.M, __builtin_fmaf(q, q, pr2), -rt);
+    const float m2 = __builtin_fmaf(H2, k.a2, __builtin_fmaf(-Lis2, Lis2, k.a2));
+    const float scm = s2sc.y * m2;
+    o.dp = pk_bc(-iS) * (f32x2){b, scm};                                        // [dp_r, dp_theta]
+    return o;
+}
+
+// [sin, cos] of th0 + d from cs0 = [cos, sin](th0); sincos_shift<float, false>
+__device__ __forceinline__ f32x2 sincos_shift_pk(f32x2 cs0, float d)
+{
+#pragma clang fp contract(off)
+    const float z = d * d;
+    f32x2 pp = pk_fma(pk_bc(z), (f32x2){8.3333333333e-3f, -1.3888888889e-3f}, (f32x2){-1.6666666667e-1f, 4.1666666667e-2f});
+    pp = pk_fma(pp, pk_bc(z), (f32x2){-0.0f, -0.5f});                            // [ps z, pc]
+    const float sd = __builtin_fmaf(pp.x, d, d);
+    const float cd = __builtin_fmaf(pp.y, z, 1.0f);
+    const f32x2 x = pk_bc(sd) * cs0;                                            // [c0 sd, s0 sd]
+    return pk_fma(__builtin_shufflevector(cs0, cs0, 1, 0), pk_bc(cd), (f32x2){x.x, -x.y}); // [s0 cd + c0 sd, c0 cd - s0 sd]
+}
+
+__device__ __forceinline__ State5<float> kerr_rk4_step_fast_pk(const KerrConsts<float> &k, const RayConsts<float> &rc,
+                                                               const State5<float> &y, float h, float &min_r, float &max_d)
+{
+#pragma clang fp contract(off)
+    float s0, c0;
+    M<float>::sincos(y.th, s0, c0);
+    const f32x2 cs0 = {c0, s0}, yp = {y.pr, y.pth}, yrt = {y.r, y.th};
+    PkStage g = kerr_rhs_pk(k, rc, y.r, (f32x2){s0, c0}, yp);
+    f32x2 a_rt = {g.dr, g.dth}, a_p = g.dp; // running k1 + 2 k2 + 2 k3 + k4
+    float a_ph = g.dph;
+    const float hh = 0.5f * h;
+    float t_r = __builtin_fmaf(hh, g.dr, y.r);
+    f32x2 t_p = pk_fma(pk_bc(hh), g.dp, yp);
+    const float d2 = hh * g.dth;
+    const float r2 = t_r;
+    g = kerr_rhs_pk(k, rc, t_r, sincos_shift_pk(cs0, d2), t_p);
+    a_rt = pk_fma(pk_bc(2.0f), (f32x2){g.dr, g.dth}, a_rt);
+    a_ph = __builtin_fmaf(2.0f, g.dph, a_ph);
+    a_p = pk_fma(pk_bc(2.0f), g.dp, a_p);
+    t_r = __builtin_fmaf(hh, g.dr, y.r);
+    t_p = pk_fma(pk_bc(hh), g.dp, yp);
+    const float d3 = hh * g.dth;
+    const float r3 = t_r;
+    g = kerr_rhs_pk(k, rc, t_r, sincos_shift_pk(cs0, d3), t_p);
+    a_rt = pk_fma(pk_bc(2.0f), (f32x2){g.dr, g.dth}, a_rt);
+    a_ph = __builtin_fmaf(2.0f, g.dph, a_ph);
+    a_p = pk_fma(pk_bc(2.0f), g.dp, a_p);
+    t_r = __builtin_fmaf(h, g.dr, y.r);
+    t_p = pk_fma(pk_bc(h), g.dp, yp);
+    const float d4 = h * g.dth;
+    g = kerr_rhs_pk<true>(k, rc, t_r, sincos_shift_pk(cs0, d4), t_p);
+    min_r = __builtin_fminf(__builtin_fminf(r2, r3), t_r);
+    max_d = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d2), __builtin_fabsf(d3)), __builtin_fabsf(d4));
+    const float h6 = h * float(1.0 / 6.0);
+    // the last stage's velocities enter the sums as fused products, as in kerr_rk4_step_impl
+    const f32x2 sum_rt = pk_fma((f32x2){g.Delta, t_p.y}, (f32x2){g.iSpr, g.iS}, a_rt);
+    const f32x2 o_rt = pk_fma(pk_bc(h6), sum_rt, yrt);
+    const f32x2 o_p = pk_fma(pk_bc(h6), a_p + g.dp, yp);
+    State5<float> o;
+    o.r = o_rt.x; o.th = o_rt.y;
+    o.ph = __builtin_fmaf(h6, __builtin_fmaf(g.iS, g.u, a_ph), y.ph);
+    o.pr = o_p.x; o.pth = o_p.y;
+    return o;
+}
+
+// LONE = true: the packed form where there is one (float32); the scalar step otherwise
+template <typename T, bool LONE>
+__device__ __forceinline__ State5<T> kerr_rk4_step_fast_for(const KerrConsts<T> &k, const RayConsts<T> &rc,
+                                                            const State5<T> &y, T h, T &min_r, T &max_d)
+{
+    if constexpr (LONE && sizeof(T) == 4) return kerr_rk4_step_fast_pk(k, rc, y, h, min_r, max_d);
+    else return kerr_rk4_step_fast(k, rc, y, h, min_r, max_d);
 }
 
 // Step-size rule of the reference's fixed-step RK4 tracer (metrics.py:597-611): h_base, capped in
@@ -430,8 +593,8 @@ template <typename T> __device__ __forceinline__ void ray_start(const KerrConsts
 // A lane for which `good` fails keeps its state (the general iteration redoes that step); lanes for which
 // it holds keep the step -- lanes are independent, they need not stay in lockstep.  Same arithmetic as the
 // general iteration (kerr_rk4_step_fast, same h), so which of the two paths took a step does not matter.
-// Returns the number of loop iterations (wave-uniform).
-template <typename T>
+// Returns the number of loop iterations (wave-uniform).  LONE: the wave is alone on its SIMD (packed step, above).
+template <typename T, bool LONE = false>
 __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, const RayConsts<T> &rc, RayState<T> &s,
                                                     uint32_t max_steps)
 {
@@ -447,7 +610,7 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
     auto attempt = [&](const State5<T> &from, T lam, State5<T> &to, T &h) -> bool {
         h = rc.hb;
         T min_r, max_d;
-        to = kerr_rk4_step_fast(k, rc, from, h, min_r, max_d);
+        to = kerr_rk4_step_fast_for<T, LONE>(k, rc, from, h, min_r, max_d);
         T mag = M<T>::abs(to.r) + M<T>::abs(to.th) + M<T>::abs(to.ph) + M<T>::abs(to.pr) + M<T>::abs(to.pth);
         ++done;
         return (lam <= lam_limit) & M<T>::finite(mag) & (to.r >= k.rc4) & (to.r < k.r_escape) & (min_r > k.r_cut) &

@@ -30,6 +30,11 @@ template <typename T> struct Rk4 {
     {
         return kerr_rk4_streak(k, rc, s, max_steps);
     }
+    // the same for a wavefront that is alone on its SIMD (ghost-lane phase of the integrate kernels)
+    static __device__ __forceinline__ uint32_t streak_lone(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, uint32_t max_steps)
+    {
+        return kerr_rk4_streak<T, true>(k, rc, s, max_steps);
+    }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -83,6 +88,7 @@ template <typename T, bool EXACT_CTRL = false> struct Dp45 {
     }
 
     static __device__ __forceinline__ uint32_t streak(const KerrConsts<T> &, const RayConsts<T> &, State &, uint32_t) { return 0; }
+    static __device__ __forceinline__ uint32_t streak_lone(const KerrConsts<T> &, const RayConsts<T> &, State &, uint32_t) { return 0; }
 
     // right-hand side at stage state y, whose polar angle is th0 + dth with (s0, c0) = sincos(th0).
     // CHECKED = false: without the in-line r <= r_cut and |dth| > 0.25 handling (see attempt()).

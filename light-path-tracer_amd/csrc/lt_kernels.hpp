@@ -420,7 +420,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
                 take_from_lane(rc, lead, !real);
                 sync = false;
             }
-            it += Integ::streak(k, rc, st, 64u);
+            it += Integ::streak_lone(k, rc, st, 64u);
             int e = Integ::advance(k, rc, st);
             ++it;
             if (wave_any(e != EV_RUNNING)) {
