@@ -2,7 +2,7 @@
 """What one rank of an N-GPU run does, measured on ONE GPU under benchmark conditions: for every partition p of n,
 back-to-back device-resident frames of that partition (no host copies in between, so the clocks stay up -- unlike
 tools/part_times.py, which goes through the host-pointer API and lets the GPU idle between launches).
-The N-GPU frame time is the max over p, plus the gather.   usage: part_bench.py [size] [rk4|dp45] [frames]"""
+The N-GPU frame time is the max over p, plus the gather.   usage: part_bench.py [size] [rk4|dp45] [frames] [spin a]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -12,10 +12,11 @@ import ltrace
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 integ = sys.argv[2] if len(sys.argv) > 2 else "rk4"
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+spin = float(sys.argv[4]) if len(sys.argv) > 4 else 0.9
 dev = torch.device("cuda:0")
 fov = np.radians(40.0)
 cam = ltrace.Camera(size, size, fov, fov, 0.0, 0.0, 50.0, np.pi / 2)
-met = ltrace.Metric(1, 0, 1.0, 0.9)
+met = ltrace.Metric(1, 0, 1.0, spin)
 stream = torch.cuda.current_stream()
 for n in (1, 2, 4, 8):
     res = []

@@ -26,6 +26,7 @@ if [ "${1:-}" = measure ]; then
     bash tools/pipeline_bench.sh > $G/pipeline.txt 2>&1
     python3 tools/part_bench.py 4096 rk4 > $G/part_bench_rk4.log 2>&1
     python3 tools/part_bench.py 4096 dp45 > $G/part_bench_dp45.log 2>&1
+    python3 tools/part_bench.py 8192 rk4 5 0.99 > $G/part_bench_8192.log 2>&1
     python3 tools/balance_bench.py 4096 > $G/balance_bench.log 2>&1
     for p in 25 205 50 75 0; do python3 bench.py --size 4096 --no-cpu-baseline --no-extras --steps 10 --emulate-parts 256 --emulate-part $p 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.readline()); print('row block $p alone (16 rows x 4096): integrate', d['roofline']['avg_launch_ms'], 'ms')"; done > $G/single_blocks.log 2>&1
@@ -68,6 +69,7 @@ elif [ "${1:-}" = collect ]; then
       echo "# tools/lone_pace_by_lanes.py, defaults (ghost lanes after 1024 iterations)"; grep -v amdgpu $G/lone_lanes_on.log
       echo "# tools/part_bench.py 4096 rk4: one rank of an N-GPU run under benchmark conditions"; grep n_parts $G/part_bench_rk4.log
       echo "# tools/part_bench.py 4096 dp45 (float64)"; grep n_parts $G/part_bench_dp45.log
+      echo "# tools/part_bench.py 8192 rk4 5 0.99 (config 5: Kerr a = 0.99, 8192 x 8192, rows sharded across 8 GPUs)"; grep n_parts $G/part_bench_8192.log
       echo "# single 16-row blocks rendered alone (bench.py --emulate-parts 256 --emulate-part b): blocks 25, 205, 50, 75 hold the four longest rays, block 0 none"; cat $G/single_blocks.log
       echo "# tools/balance_bench.py 4096: cost-weighted row-block assignment (sharding.balance_blocks, lt_opts.block_owner) against block-cyclic, every rank emulated on one GPU"; grep -v amdgpu $G/balance_bench.log; } > $P/${R}_long_ray_chain.txt
     { echo "# $R: host-pointer lt_render, 4096x4096, RGBA8 destination only (tools/e2e_frame.py): what python image_lens.py pays per frame"
