@@ -1,6 +1,11 @@
 #!/bin/bash
-# A/B of two library builds on one box, interleaved: tools/scratch/ab.sh libA.so libB.so   (files under .variants/)
-for rep in 1 2 3; do for l in "$@"; do
-  for sz in 2048 4096; do LTRACE_LIB=$PWD/.variants/$l python bench.py --size $sz --no-cpu-baseline --no-extras --steps 20 | python -c "
-import json,sys; d=json.loads(sys.stdin.readline()); print('$l size', d['config']['rays_per_frame'], d['value'], d['roofline']['avg_launch_ms'], d['config']['escaped'], d['config']['captured'])"; done
-done; done
+# interleaved A/B of builds (file names under lib/) on the headline frame:  ab.sh libA.so libB.so [bench args]
+L=$PWD/light-path-tracer_amd/lib
+A=$1; B=$2; shift 2
+for rep in 1 2 3; do
+  for lib in $A $B; do
+    LTRACE_LIB=$L/$lib python bench.py --no-extras --no-cpu-baseline "$@" 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib  %.1f Mrays/s  %.3f ms  integrate %.3f ms' % (d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms']))"
+  done
+done
