@@ -24,6 +24,13 @@
 
 using namespace lt;
 
+// compiled in lt_k2_lone.hip (its own translation unit: another instruction scheduler, see there)
+namespace lt {
+extern template __global__ void k_kerr_direct<float, Rk4<float>>(KerrConsts<float>, const typename Vec4<float>::type *__restrict__,
+                                                                 typename Vec4<float>::type *__restrict__, typename Vec4<float>::type *__restrict__,
+                                                                 int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__);
+}
+
 // ---------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------

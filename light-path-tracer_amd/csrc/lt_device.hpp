@@ -494,13 +494,17 @@ __device__ __forceinline__ f32x2 sincos_shift_pk(f32x2 cs0, float d)
     return pk_fma(__builtin_shufflevector(cs0, cs0, 1, 0), pk_bc(cd), (f32x2){x.x, -x.y}); // [s0 cd + c0 sd, c0 cd - s0 sd]
 }
 
+// cs0 = [cos, sin](y.th) comes in and [cos, sin] of the new polar angle goes out: the argument reduction of the NEXT
+// step's base angle depends on nothing but o.th, which is ready well before the last stage's momenta are, so written
+// here the scheduler can run it beside the tail of the last right-hand side instead of at the head of the next step,
+// where everything waits for it (a lone wave is bound by the depth of its dependence chains).
 __device__ __forceinline__ State5<float> kerr_rk4_step_fast_pk(const KerrConsts<float> &k, const RayConsts<float> &rc,
-                                                               const State5<float> &y, float h, float &min_r, float &max_d)
+                                                               const State5<float> &y, f32x2 cs0, float h, float &min_r,
+                                                               float &max_d, f32x2 &cs_out)
 {
 #pragma clang fp contract(off)
-    float s0, c0;
-    M<float>::sincos(y.th, s0, c0);
-    const f32x2 cs0 = {c0, s0}, yp = {y.pr, y.pth}, yrt = {y.r, y.th};
+    const float s0 = cs0.y, c0 = cs0.x;
+    const f32x2 yp = {y.pr, y.pth}, yrt = {y.r, y.th};
     PkStage g = kerr_rhs_pk(k, rc, y.r, (f32x2){s0, c0}, yp);
     f32x2 a_rt = {g.dr, g.dth}, a_p = g.dp; // running k1 + 2 k2 + 2 k3 + k4
     float a_ph = g.dph;
@@ -534,17 +538,38 @@ __device__ __forceinline__ State5<float> kerr_rk4_step_fast_pk(const KerrConsts<
     const f32x2 o_p = pk_fma(pk_bc(h6), a_p + g.dp, yp);
     State5<float> o;
     o.r = o_rt.x; o.th = o_rt.y;
+    {
+        float sn, cn;
+        M<float>::sincos(o.th, sn, cn);
+        asm volatile("" : "+v"(sn), "+v"(cn)); // (pins the evaluation to this step: the compiler would sink it to its use, the head of the next one)
+        cs_out = (f32x2){cn, sn};
+    }
     o.ph = __builtin_fmaf(h6, __builtin_fmaf(g.iS, g.u, a_ph), y.ph);
     o.pr = o_p.x; o.pth = o_p.y;
     return o;
 }
 
+// What a streak carries from one step to the next besides the state: nothing, or (packed step) [cos, sin] of the polar angle
+template <typename T, bool LONE> struct StepCarry {
+    __device__ __forceinline__ void init(T) {}
+};
+template <> struct StepCarry<float, true> {
+    f32x2 cs;
+    __device__ __forceinline__ void init(float th)
+    {
+        float s, c;
+        M<float>::sincos(th, s, c);
+        cs = (f32x2){c, s};
+    }
+};
+
 // LONE = true: the packed form where there is one (float32); the scalar step otherwise
 template <typename T, bool LONE>
-__device__ __forceinline__ State5<T> kerr_rk4_step_fast_for(const KerrConsts<T> &k, const RayConsts<T> &rc,
-                                                            const State5<T> &y, T h, T &min_r, T &max_d)
+__device__ __forceinline__ State5<T> kerr_rk4_step_fast_for(const KerrConsts<T> &k, const RayConsts<T> &rc, const State5<T> &y,
+                                                            const StepCarry<T, LONE> &cin, T h, T &min_r, T &max_d,
+                                                            StepCarry<T, LONE> &cout)
 {
-    if constexpr (LONE && sizeof(T) == 4) return kerr_rk4_step_fast_pk(k, rc, y, h, min_r, max_d);
+    if constexpr (LONE && sizeof(T) == 4) return kerr_rk4_step_fast_pk(k, rc, y, cin.cs, h, min_r, max_d, cout.cs);
     else return kerr_rk4_step_fast(k, rc, y, h, min_r, max_d);
 }
 
@@ -607,10 +632,10 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
     // fails the test and takes its last, shorter step in the general iteration.  With h invariant the step's h / 2 and
     // h / 6, the subtraction and the min leave the loop.
     const T lam_limit = k.lambda_max - rc.hb;
-    auto attempt = [&](const State5<T> &from, T lam, State5<T> &to, T &h) -> bool {
+    auto attempt = [&](const State5<T> &from, const StepCarry<T, LONE> &cfrom, T lam, State5<T> &to, StepCarry<T, LONE> &cto, T &h) -> bool {
         h = rc.hb;
         T min_r, max_d;
-        to = kerr_rk4_step_fast_for<T, LONE>(k, rc, from, h, min_r, max_d);
+        to = kerr_rk4_step_fast_for<T, LONE>(k, rc, from, cfrom, h, min_r, max_d, cto);
         T mag = M<T>::abs(to.r) + M<T>::abs(to.th) + M<T>::abs(to.ph) + M<T>::abs(to.pr) + M<T>::abs(to.pth);
         ++done;
         return (lam <= lam_limit) & M<T>::finite(mag) & (to.r >= k.rc4) & (to.r < k.r_escape) & (min_r > k.r_cut) &
@@ -620,9 +645,11 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
     // the loop body is two attempts, A -> B and B -> A, each followed by the one wave-uniform test.  On leaving,
     // a lane keeps the attempted state if its own predicate held, its previous state otherwise.
     State5<T> b;
+    StepCarry<T, LONE> ca, cb;
+    ca.init(s.y.th);
     T h;
     for (;;) {
-        bool good = attempt(s.y, s.lam, b, h);
+        bool good = attempt(s.y, ca, s.lam, b, cb, h);
         if (!wave_all(good) | (done >= max_steps)) {
             s.y.r = good ? b.r : s.y.r; s.y.th = good ? b.th : s.y.th; s.y.ph = good ? b.ph : s.y.ph;
             s.y.pr = good ? b.pr : s.y.pr; s.y.pth = good ? b.pth : s.y.pth;
@@ -632,7 +659,7 @@ __device__ __forceinline__ uint32_t kerr_rk4_streak(const KerrConsts<T> &k, cons
         }
         s.lam += h;
         ++s.steps;
-        good = attempt(b, s.lam, s.y, h);
+        good = attempt(b, cb, s.lam, s.y, ca, h);
         if (!wave_all(good) | (done >= max_steps)) {
             s.y.r = good ? s.y.r : b.r; s.y.th = good ? s.y.th : b.th; s.y.ph = good ? s.y.ph : b.ph;
             s.y.pr = good ? s.y.pr : b.pr; s.y.pth = good ? s.y.pth : b.pth;

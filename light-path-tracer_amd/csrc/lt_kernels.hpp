@@ -969,6 +969,7 @@ __global__ void __launch_bounds__(256) k_probe_rk4_step(KerrConsts<T> k_in, int 
 
 #endif // LT_PROBES
 
+#ifndef LT_KERNEL_TEMPLATES_ONLY // (lt_k2_lone.hip: a second translation unit must not define the plain kernels again)
 // Row scatter after the multi-GPU gather: partition rows -> full frame, 16 B per lane where possible.
 __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__restrict__ full, int rows_local,
                                int64_t row_bytes, int row_block, int n_parts, int part_id)
@@ -986,8 +987,9 @@ __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__rest
         for (int64_t j = i; j < i + 16 && j < row_bytes; ++j) dst[j] = src[j];
     }
 }
+#endif // LT_KERNEL_TEMPLATES_ONLY
 
-#ifdef LT_PROBES
+#if defined(LT_PROBES) && !defined(LT_KERNEL_TEMPLATES_ONLY)
 // FP32 VALU issue-rate probe: 8 independent FMA chains per lane.
 __global__ void __launch_bounds__(256) k_valu_probe(int mode, int iters, float *sink)
 {

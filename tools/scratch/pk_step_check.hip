@@ -14,7 +14,9 @@ __global__ void k(KerrConsts<float> kc, const float *in, uint32_t *out, float *v
     RayConsts<float> rc = make_ray_consts(kc, in[6 * i + 4], false);
     float mr, md, mr2, md2;
     State5<float> a = kerr_rk4_step_fast(kc, rc, y, rc.hb, mr, md);
-    State5<float> b = kerr_rk4_step_fast_pk(kc, rc, y, rc.hb, mr2, md2);
+    float sy, cy; M<float>::sincos(y.th, sy, cy);
+    f32x2 cs_next;
+    State5<float> b = kerr_rk4_step_fast_pk(kc, rc, y, (f32x2){cy, sy}, rc.hb, mr2, md2, cs_next);
     auto ne = [](float x, float z) { return __float_as_uint(x) != __float_as_uint(z); };
     out[i] = (ne(a.r, b.r) ? 1u : 0u) | (ne(a.th, b.th) ? 2u : 0u) | (ne(a.ph, b.ph) ? 4u : 0u) | (ne(a.pr, b.pr) ? 8u : 0u) | (ne(a.pth, b.pth) ? 16u : 0u) |
              (ne(mr, mr2) ? 32u : 0u) | (ne(md, md2) ? 64u : 0u);
