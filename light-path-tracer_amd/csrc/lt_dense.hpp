@@ -48,7 +48,7 @@ __device__ __forceinline__ void rhs8_sc(const DenseConsts &k, const double *y, d
     const double r2 = r * r, ra = r2 + k.a2;
     const double Sigma = r2 + k.a2 * c * c, Delta = ra - 2.0 * k.M * r;
     // one division for the three reciprocals (each float64 division is ~12 instructions around a quarter-rate v_rcp_f64)
-    const double SD = Sigma * Delta, t = 1.0 / (SD * s2);
+    const double SD = Sigma * Delta, t = M<double>::rcp_pos(SD * s2); // (> 0 outside r_zero; sin^2 = 0 gives NaN as the division's inf * 0 did)
     const double iS = (Delta * s2) * t, iD = (Sigma * s2) * t, is2 = SD * t;
     const double P = E * ra - k.a * L, D = L - k.a * E * s2;
     const double PD = P * iD, Ds = D * is2;
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             double ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * h;
-            e[c] = ec / (k.atol + fmax(fabs(y[c]), fabs(yn[c])) * k.rtol);
+            e[c] = ec * M<double>::rcp_pos(k.atol + fmax(fabs(y[c]), fabs(yn[c])) * k.rtol); // (>= atol > 0)
         }
         const double err = rms8(e);
         if (!(err < 1.0)) { // rejected: this lane retries in the next iteration with a smaller step
