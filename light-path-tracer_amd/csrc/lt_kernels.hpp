@@ -356,12 +356,13 @@ template <typename S> __device__ __forceinline__ void take_from_lane(S &s, uint3
 //
 // Ghost lanes (integrators with Integ::GHOST_LANES).  A wavefront still running after `long_iters` iterations hosts
 // one of the few very long rays; the launch cannot end before it does, and at the end of the launch that wave is alone
-// on its SIMD with one lane left.  Measured on MI355X (tools/scratch/lone_pace_by_lanes.py): a lone
+// on its SIMD with one lane left.  Measured on MI355X (tools/lone_pace_by_lanes.py): a lone
 // wavefront with 40 or more of its 64 lanes enabled takes 0.557 us per RK4 step on every CU; with 32 or fewer enabled
 // the same instruction stream takes 0.557 to 0.75 us depending on the CU it landed on.  So a long wave does not let
 // its finished lanes idle: from `long_iters` on, a lane whose ray has ended stores its result and then shadows the
 // first lane that is still running (same state, same constants -- a bitwise twin, so every wave-level predicate is what
-// it would have been without it).  Ghosts never store; no output depends on them.
+// it would have been without it).  Ghosts never store; no output depends on them.  In that phase the streak takes the
+// step in its lone-wave form (Integ::streak_lone: packed float32 where there is one, lt_device.hpp) -- same bits.
 template <typename T, typename Integ>
 __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
