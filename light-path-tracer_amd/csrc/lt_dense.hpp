@@ -82,10 +82,6 @@ __device__ __forceinline__ void rhs8_near(const DenseConsts &k, const double *y,
     rhs8_sc(k, y, s, c, d);
 }
 
-// err^(-1/5) of the step controller as exp2(-0.2 log2(err)): half the instructions of the general pow(), relative
-// error ~1e-15 -- it scales the next step size, where solve_ivp's own libm differs from ours by as much
-__device__ __forceinline__ double pow_m02(double x) { return exp2(-0.2 * log2(x)); }
-
 __device__ __forceinline__ double rms8(const double *x)
 {
     double s = 0;

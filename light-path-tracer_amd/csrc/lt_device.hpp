@@ -326,6 +326,26 @@ __device__ __forceinline__ void kerr_rhs(const KerrConsts<T> &k, const RayConsts
     kerr_rhs_sc(k, rc, r, s, c, pr, pth, dr, dth, dph, dpr, dpth);
 }
 
+// x^(-1/5) for the float64 step controllers (dense tracks: err^(-1/5), where solve_ivp's own libm differs from ours in
+// the last bits too; DP45 with the reference's controller: err_norm^(-0.2)).  A float32 seed from the hardware log2 / exp2 (relative error ~1e-6) and two Newton steps on
+// y^-5 = x,  y <- y + y (1 - x y^5) / 5  (quadratic: 1e-6 -> 3e-12 -> 1e-22, then the rounding of the evaluation,
+// ~1 ulp): 18 instructions where exp2(-0.2 log2(x)) in float64 library code takes ~110.  Outside [1e-6, 1e4] the
+// controller clamps the factor anyway (0.9 y > 10, or < 0.2), so any value on the right side of the clamp does; a NaN
+// comes out as a NaN, as before.
+__device__ __forceinline__ double pow_m02(double x)
+{
+    const float xf = (float)x;
+    double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(xf));
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double y2 = y * y, y5 = (y2 * y2) * y;
+        y = __builtin_fma(y, 0.2 * __builtin_fma(-x, y5, 1.0), y);
+    }
+    y = x < 1e-6 ? 100.0 : y;
+    y = x > 1e4 ? 0.1 : y;
+    return y;
+}
+
 // sin and cos of th0 + d from (s0, c0) = sincos(th0): the stage states of a Runge-Kutta step differ from
 // the step's base state by h * (a small angular velocity), so the 25-instruction argument reduction +
 // polynomials shrink to an 11-instruction rotation.  The wave falls back to the full evaluation in the

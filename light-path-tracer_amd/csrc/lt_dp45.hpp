@@ -72,9 +72,9 @@ template <typename T> struct Dp45State {
 template <typename T, bool EXACT_CTRL = false> struct Dp45 {
     using State = Dp45State<T>;
     static constexpr int EVALS_FIXED = 1, EVALS_PER_STEP = 6;
-    // hold the register allocation at 256 (it sits just above); the float64 pow of the exact controller does not fit
-    // there without spilling, so that variant runs one wave per SIMD
-    static constexpr int MIN_WAVES_PER_SIMD = EXACT_CTRL ? 1 : 2;
+    // hold the register allocation at 256 (it sits just above); the exact controller fits there too since its
+    // err_norm ** -0.2 is pow_m02 (lt_device.hpp) and no longer the float64 library pow
+    static constexpr int MIN_WAVES_PER_SIMD = 2;
     static constexpr bool GHOST_LANES = false;   // adaptive steps: no ray is long enough to be alone on the chip
 
     static __device__ __forceinline__ void start(const KerrConsts<T> &k, const RayConsts<T> &rc, State &s, T p_r, T p_th)
@@ -158,8 +158,9 @@ template <typename T, bool EXACT_CTRL = false> struct Dp45 {
             T ei = h * (E1 * k1[i] + E3 * k3[i] + E4 * k4[i] + E5 * k5[i] + E6 * k6[i] + E7 * k7[i]);
             T sc = atol + rtol * M<T>::max(M<T>::abs(y[i]), M<T>::abs(nxt[i]));
             // ei / sc with a float reciprocal (relative error 1e-7): the error norm only gates accept / reject
-            // and scales h; a float64 division is ~25 instructions, five of them per attempt
-            T q = EXACT_CTRL ? ei / sc : ei * (T)M<float>::rcp_pos((float)sc);
+            // and scales h; a float64 division is ~12 instructions, five of them per attempt.  The exact controller
+            // takes the float64 reciprocal (seed + two Newton steps, within an ulp).
+            T q = EXACT_CTRL ? ei * (T)M<double>::rcp_pos((double)sc) : ei * (T)M<float>::rcp_pos((float)sc);
             err_sq += q * q;
         }
     }
@@ -198,8 +199,8 @@ template <typename T, bool EXACT_CTRL = false> struct Dp45 {
         T grow;
         bool reject, tiny;
         if (EXACT_CTRL) {
-            const double err_norm = __builtin_sqrt((double)err_sq / 5.0);          // metrics.py:514
-            grow = (T)(0.9 * pow(err_norm, -0.2));                                  // metrics.py:518, :564
+            const double err_norm = __builtin_sqrt((double)err_sq * 0.2);          // metrics.py:514 (err_sq / 5 to an ulp)
+            grow = (T)(0.9 * pow_m02(err_norm));                                    // metrics.py:518, :564 (err_norm ** -0.2)
             reject = err_norm > 1.0;
             tiny = err_norm < 1e-10;
         } else {
