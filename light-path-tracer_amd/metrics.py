@@ -23,10 +23,12 @@ import numpy as np
 
 import ltrace
 
-# Backend defaults.  'dp45' (float64) is the reference's production Kerr integrator
-# (metrics.py:419-567) and therefore the drop-in default; 'rk4' + precision 32 is the north-star
-# kernel (reference metrics.py:570-658, float32), about 2.4x faster per ray -- what bench.py measures.
-DEFAULT_KERR_INTEGRATOR = "dp45"
+# Backend defaults.  DP45 (float64) is the reference's production Kerr integrator (metrics.py:419-567) and therefore
+# the drop-in default -- with the step controller evaluated in float64 as the reference writes it ('dp45_exact': every
+# accept / reject decision of the reference's own run is reproduced; since round 2 it costs 4 % over 'dp45', whose
+# controller is float32); 'rk4' + precision 32 is the north-star kernel (reference metrics.py:570-658, float32),
+# about 1.7x faster per ray -- what bench.py measures.
+DEFAULT_KERR_INTEGRATOR = "dp45_exact"
 DEFAULT_PRECISION = 32
 DEFAULT_SCHEDULE = "direct"
 
