@@ -28,7 +28,7 @@ using namespace lt;
 namespace lt {
 extern template __global__ void k_kerr_direct<float, Rk4<float>>(KerrConsts<float>, const typename Vec4<float>::type *__restrict__,
                                                                  typename Vec4<float>::type *__restrict__, typename Vec4<float>::type *__restrict__,
-                                                                 int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__);
+                                                                 int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -522,6 +522,19 @@ struct StampDump {
     }
 };
 
+// Wavefront slots of the device for a kernel launched with 64-thread workgroups (0 if the query fails: the caller then
+// launches one workgroup per tile).  Asked once per kernel.
+template <auto Kernel> static int resident_slots()
+{
+    static const int slots = [] {
+        int per_cu = 0, cus = 0;
+        if (cu_count(&cus) != LT_OK) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)Kernel, 64, 0) != hipSuccess || per_cu <= 0) return 0;
+        return per_cu * cus;
+    }();
+    return slots;
+}
+
 template <typename T>
 static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lambda_max, const Workspace &w,
                             int64_t n_q, hipStream_t s, uint64_t *kstats)
@@ -543,12 +556,32 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
                                              return (b == 64 || b == 128 || b == 256) ? b : 64; }();
             unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
             static const int long_iters = env_int("LT_D_LONG", 1024);
+            // Tiles are handed out from a queue head to a grid that fills the chip once (k_kerr_direct); LT_D_PERSIST=0
+            // or wider workgroups: one workgroup per tile, as in round 1.
+            static const int persist = env_int("LT_D_PERSIST", 1);
+            unsigned long long *head = nullptr;
+            auto resident_grid = [&](int slots) { // (a launch that fits the chip needs no queue)
+                if (slots > 0 && (unsigned)slots < kgrid) { kgrid = (unsigned)slots; head = w.head; }
+            };
+            const bool want_queue_head = persist && k2_block == 64;
             if ((rc = sd.begin((size_t)(n_q / 64)))) return rc;
             if constexpr (sizeof(T) == 8) {
-                if (dp45 && !exact) k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats);
-                if (exact) k_kerr_direct<T, Dp45<T, true>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats);
+                if (dp45 && !exact) {
+                    if (want_queue_head) resident_grid(resident_slots<k_kerr_direct<T, Dp45<T>>>());
+                    if (head) HIP_TRY(hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+                    k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats, head);
+                }
+                if (exact) {
+                    if (want_queue_head) resident_grid(resident_slots<k_kerr_direct<T, Dp45<T, true>>>());
+                    if (head) HIP_TRY(hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+                    k_kerr_direct<T, Dp45<T, true>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats, head);
+                }
             }
-            if (!dp45) k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats);
+            if (!dp45) {
+                if (want_queue_head) resident_grid(resident_slots<k_kerr_direct<T, Rk4<T>>>());
+                if (head) HIP_TRY(hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+                k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats, head);
+            }
         } else {
             int cus;
             if ((rc = cu_count(&cus))) return rc;

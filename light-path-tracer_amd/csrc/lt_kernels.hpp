@@ -363,20 +363,38 @@ template <typename S> __device__ __forceinline__ void take_from_lane(S &s, uint3
 // first lane that is still running (same state, same constants -- a bitwise twin, so every wave-level predicate is what
 // it would have been without it).  Ghosts never store; no output depends on them.  In that phase the streak takes the
 // step in its lone-wave form (Integ::streak_lone: packed float32 where there is one, lt_device.hpp) -- same bits.
+//
+// Tiles are handed out, not assigned.  With `head` set the grid only fills the chip once (one wavefront per resident
+// slot) and every wavefront takes tile after tile from the queue head with one atomic each, in queue order, until the
+// queue is empty.  Measured (tools/scratch/tail_analyze.py): the dispatcher deals workgroups to the
+// eight XCDs round-robin, the XCDs hold clocks up to 6 % apart under this load (1 994 ... 2 125 MHz in one launch), so with
+// one workgroup per tile the fastest XCD had finished its eighth of the frame 0.8 ms before the slowest -- 3.6 % of the
+// chip idle on average -- and every finished wave left its slot empty until the dispatcher had set up the next one
+// (4.7 of 5 slots occupied).  A wave that takes the next tile itself does neither.  `head` == nullptr: one tile per
+// workgroup, tile = workgroup index (the batch twins' short launches, LT_D_PERSIST=0).
 template <typename T, typename Integ>
 __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
                                                          uint32_t long_iters, uint4 *__restrict__ stamps,
-                                                         uint64_t *__restrict__ kstats)
+                                                         uint64_t *__restrict__ kstats, unsigned long long *__restrict__ head)
 {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_q) return;
-    uint64_t t0 = stamps ? wave_clock() : 0, c0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
-    WaveMeter meter;
-    meter.begin(kstats, q >> 6);
     KerrConsts<T> k = k_in;
     pin_consts(k);
+    const int lane = (int)(threadIdx.x & 63u);
+    int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (;;) {
+    if (head) {
+        unsigned long long w = 0;
+        if (lane == 0) w = atomicAdd(head, 1ull);
+        tile = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+                         (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
+    }
+    const int64_t q = tile * 64 + lane;
+    if (q >= n_q) return; // n_q is a multiple of 64: the whole wave leaves (queue empty, or a workgroup past the end)
+    uint64_t t0 = stamps ? wave_clock() : 0, c0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
+    WaveMeter meter;
+    meter.begin(kstats, tile);
     typename Vec4<T>::type rec = ic[q];
     int flags = (int)rec.w;
     typename Integ::State st;
@@ -384,12 +402,12 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
     st.steps = 0;
     int ev = (flags & FLAG_PAD) ? EV_PAD : EV_INVALID;
     uint32_t wave_iters = 0; // loop iterations this wave issued (streak attempts + general iterations)
+    bool raised = false;     // wave-uniform: the wave has raised its issue priority for this tile
     RayConsts<T> rc = make_ray_consts(k, rec.z, (flags & FLAG_REFINE) != 0);
     if (flags & FLAG_OK) {
         Integ::start(k, rc, st, rec.x, rec.y);
         // The iteration counter is uniform over the lanes still in the loop (SGPR), so the checks on it cost no VALU.
         uint32_t it = 0;
-        bool raised = false;
         do {
             it += Integ::streak(k, rc, st, 64u);
             ev = Integ::advance(k, rc, st);
@@ -410,6 +428,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
     bool real = ev == EV_RUNNING; // only with ghost lanes: this lane's ray is still running
     if (Integ::GHOST_LANES && wave_any(real)) {
         __builtin_amdgcn_s_setprio(3);
+        raised = true;
         if (!real) store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
         uint32_t lead = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(real));
         uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)wave_iters, (int)lead); // every running lane holds the same count
@@ -439,7 +458,10 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
         store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
     }
     meter.end(kstats, wave_iters);
-    if (stamps) write_stamp(stamps, q >> 6, t0, steps, c0);
+    if (stamps) write_stamp(stamps, tile, t0, steps, c0);
+    if (!head) return;
+    if (__builtin_amdgcn_ballot_w64(raised)) __builtin_amdgcn_s_setprio(0); // back to the bulk's priority for the next tile
+    }
 }
 
 // Queue schedule: persistent wavefronts.  The grid is sized to fill the chip once (blocks = CUs x
