@@ -163,10 +163,23 @@ struct DenseOut {
 // lanes from a track queue was built and measured: utilisation 0.73, 7 % fewer instructions, but
 // 11 % MORE time -- its service code (event location, track start-up) runs at 8/64 lanes and the denser stream
 // clocks lower -- so it is not the kernel that ships.
-__global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o)
+// Blocks of 64 tracks are handed out from a queue head to a grid that fills the chip once, like the tiles of
+// k_kerr_direct (the XCDs run at different clocks; a workgroup per block leaves the fastest idle at the end);
+// head == nullptr: one workgroup per block.
+__global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o,
+                                                                     unsigned long long *__restrict__ head)
 {
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (i >= k.n) return;
+    int64_t block = blockIdx.x;
+    for (;;) {
+    if (head) {
+        unsigned long long w = 0;
+        if (threadIdx.x == 0) w = atomicAdd(head, 1ull);
+        block = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+                          (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
+    }
+    if (block * 64 >= k.n) return;
+    const int64_t i = block * 64 + threadIdx.x;
+    if (i < k.n) {
     // Dormand-Prince tableau (Dormand & Prince 1980) and Shampine's dense-output matrix
     constexpr double A21 = 1.0 / 5, A31 = 3.0 / 40, A32 = 9.0 / 40, A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9,
                      A51 = 19372.0 / 6561, A52 = -25360.0 / 2187, A53 = 64448.0 / 6561, A54 = -212.0 / 729,
@@ -338,6 +351,9 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
     o.count[i] = n_pts;
     o.status[i] = (int8_t)status;
     o.nfev[i] = nfev;
+    }
+    if (!head) return;
+    }
 }
 
 // probe of rhs8 for the parity tests
