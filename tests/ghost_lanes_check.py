@@ -35,6 +35,16 @@ def main():
             ltrace.trace_batch_kerr(1.0, 0.9, 50.0, al, th, np.pi / 2, 5000.0, rf, fa, w, integrator="rk4", precision=prec,
                                     schedule=sched)
             h.update(fa.tobytes()); h.update(w.tobytes())
+    if os.environ.get("LT_CHECK_BIG"):
+        # more tiles than the chip has wavefront slots (5 120 for float32 RK4, 2 048 for the float64 integrators): the
+        # launches that hand tiles out from a queue head (LT_D_PERSIST, k_kerr_direct)
+        W, H = 1100, 900
+        cam = ltrace.Camera(W, H, 2 * np.arctan(np.tan(fov_v / 2) * W / H), fov_v, 0.0, 0.0, 50.0, np.pi / 2)
+        for integ, prec in (("rk4", 32), ("dp45", 64)):
+            out = ltrace.render(cam, ltrace.Metric(1, 0, 1.0, 0.9), ltrace.default_opts(integrator=integ, precision=prec),
+                                want=("fa", "winding", "status", "steps", "rgba"))
+            for name in ("fa", "winding", "status", "steps", "rgba"):
+                h.update(np.ascontiguousarray(out[name]).tobytes())
     print("digest", h.hexdigest(), flush=True)
     return 0
 
