@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Analyse LT_STAMPS_FILE output: wave concurrency over time, per-wave duration vs steps."""
+"""Analyse LT_STAMPS_FILE output: one stamp per 8x8 tile (direct schedule: the wavefront that traced it, from taking the
+tile to storing its last ray) or per wavefront (queue schedule): concurrency over time, duration vs steps."""
 import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint32).reshape(-1, 4)
