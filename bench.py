@@ -110,7 +110,7 @@ def _free_port():
 
 def launch_ranks(args, argv):
     """Parent of an N-rank run: no GPU call is made in this process (device_count() does not initialise one)."""
-    if not args.stub_render:
+    if not args.stub_render and not os.environ.get("LT_BENCH_DEVICES"):
         import torch
         have = torch.cuda.device_count()
         if have < args.gpus:
@@ -314,19 +314,47 @@ def main(argv=None):
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (no CPU fallback)", file=sys.stderr)
         return 2
-    if local_rank >= torch.cuda.device_count():
-        print(f"bench.py: rank {rank} wants GPU {local_rank} but the node has {torch.cuda.device_count()}", file=sys.stderr)
+    # LT_BENCH_DEVICES="0,0": rehearsal of the N-rank path on fewer GPUs (ranks share devices; only with --backend gloo,
+    # RCCL refuses two ranks on one device).  Never set by the driver; the JSON says so when it is.
+    dev_map = os.environ.get("LT_BENCH_DEVICES")
+    dev_index = int(dev_map.split(",")[local_rank]) if dev_map else local_rank
+    if dev_index >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants GPU {dev_index} but the node has {torch.cuda.device_count()}", file=sys.stderr)
         return 2
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     rccl_world = 1
+    staged = False   # gloo moves tensors through the host: all_gather / gather of device tensors are staged by hand
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=args.backend or "nccl", device_id=dev)
+        backend = args.backend or "nccl"
+        if dev_map and backend == "nccl":
+            print("bench.py: LT_BENCH_DEVICES is a rehearsal switch and needs --backend gloo", file=sys.stderr)
+            return 2
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+            staged = True
         rccl_world = dist.get_world_size()
         if rccl_world != args.gpus:
             print(f"bench.py: the process group has {rccl_world} ranks, --gpus {args.gpus}", file=sys.stderr)
             return 2
+
+    def all_reduce(t, op):
+        if not staged:
+            dist.all_reduce(t, op=op)
+        else:
+            c = t.cpu(); dist.all_reduce(c, op=op); t.copy_(c)
+
+    def all_gather(out, t):
+        if not staged:
+            dist.all_gather(out, t)
+        else:
+            co = [torch.zeros_like(t, device="cpu") for _ in out]
+            dist.all_gather(co, t.cpu())
+            for o_, c_ in zip(out, co):
+                o_.copy_(c_)
 
     size = args.size
     fov = float(np.radians(40.0))
@@ -361,8 +389,8 @@ def main(argv=None):
         cost_t[mine_blocks] = per_row_sum.view(-1, rb).sum(dim=1)
         chain_t[mine_blocks] = per_row_max.view(-1, rb).max(dim=1).values
         if world > 1:
-            dist.all_reduce(cost_t, op=dist.ReduceOp.SUM)
-            dist.all_reduce(chain_t, op=dist.ReduceOp.SUM)
+            all_reduce(cost_t, dist.ReduceOp.SUM)
+            all_reduce(chain_t, dist.ReduceOp.SUM)
         owner = sharding.balance_blocks(cost_t.cpu().numpy(), chain_t.cpu().numpy(), n_parts, chain_cost=args.chain_cost)
         del d_steps0, st
     if owner is not None:
@@ -441,13 +469,13 @@ def main(argv=None):
                          render_ms, gather_ms], dtype=torch.float64, device=dev)
     per_rank = [mine]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(t, dist.ReduceOp.MAX)
         per_rank = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(per_rank, mine)
+        all_gather(per_rank, mine)
     elapsed = float(t.item())
     my = [int(x) for x in counters.tolist()]
     if world > 1:
-        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        all_reduce(counters, dist.ReduceOp.SUM)
     c = [int(x) for x in counters.tolist()]
     per_rank = [[float(x) for x in r.tolist()] for r in per_rank]
     slow = max(range(world), key=lambda r: per_rank[r][1])        # the rank with the longest integrate kernel
@@ -457,7 +485,7 @@ def main(argv=None):
     all_k = [mine_k]
     if world > 1:
         all_k = [torch.zeros_like(mine_k) for _ in range(world)]
-        dist.all_gather(all_k, mine_k)
+        all_gather(all_k, mine_k)
     all_k = [[int(x) for x in k.tolist()] for k in all_k]
 
     rays_per_frame = c[ltrace.STAT_RAYS] // steps
@@ -479,7 +507,7 @@ def main(argv=None):
             fence()
             tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             if world > 1:
-                dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+                all_reduce(tp, dist.ReduceOp.MAX)
             ltrace.timing_collect()
             pel = float(tp.item())
             pipelined = {"frames_in_flight": args.pipelined_extra, "value": round(rays_per_frame / (pel / steps) / 1e6, 2), "unit": "Mrays/s",
@@ -583,7 +611,8 @@ def main(argv=None):
                        "row_partition": (f"block-cyclic {rb} rows x {n_parts}" if owner is None else
                                          f"cost-weighted {rb}-row blocks x {n_parts} (rows per rank "
                                          f"{[len(ltrace.owned_rows(size, rb, owner, p)) for p in range(n_parts)]})") + (f" (emulated rank {part} on one GPU)" if n_parts != world else ""),
-                       "gather": "rccl" if world > 1 else "none",
+                       "gather": ("rccl" if not staged else "gloo, staged through the host (rehearsal)") if world > 1 else "none",
+                       **({"rehearsal_devices": dev_map} if dev_map else {}),
                        "frames_in_flight": F,
                        "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,

@@ -98,7 +98,15 @@ class FrameGather:
         if self.world == 1:
             # one partition = the whole frame, already in row order
             return self.local[: self.h]
-        dist.gather(self.local, self.parts, dst=0)
+        if self.device.type == "cuda" and dist.get_backend() == "gloo":
+            # rehearsals only (bench.py --backend gloo on a box with fewer GPUs than ranks): gloo gathers host tensors
+            host = [torch.empty_like(self.local, device="cpu") for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(self.local.cpu(), host, dst=0)
+            if self.rank == 0:
+                for p_, h_ in zip(self.parts, host):
+                    p_.copy_(h_)
+        else:
+            dist.gather(self.local, self.parts, dst=0)
         if self.rank != 0:
             return None
         elem = self.local.element_size() * self.c

@@ -18,9 +18,16 @@ import sharding             # noqa: E402
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", device_id=dev)
+    # LT_CHECK_DEVICES="0,0" + LT_CHECK_BACKEND=gloo: the same check with the ranks sharing devices and the gather staged
+    # through the host (RCCL refuses two ranks on one device) -- what a 1-GPU box can run of the N-rank path
+    dev_map = os.environ.get("LT_CHECK_DEVICES")
+    index = int(dev_map.split(",")[rank]) if dev_map else rank
+    torch.cuda.set_device(index)
+    dev = torch.device("cuda", index)
+    if os.environ.get("LT_CHECK_BACKEND", "nccl") == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group(os.environ["LT_CHECK_BACKEND"])
     W, H, rb = 1000, 777, 16                      # ragged: partitions of unequal size, last block short
     fov_v = np.radians(40.0)
     cam = ltrace.Camera(W, H, 2 * np.arctan(np.tan(fov_v / 2) * W / H), fov_v, 0.02, -0.03, 50.0, np.pi / 2)
@@ -41,7 +48,7 @@ def main():
         ltrace.render_dev(cam, met, o1, d_rgba=whole.data_ptr())
         torch.cuda.synchronize(dev)
         ok = bool(torch.equal(full, whole))
-        print(f"nccl gather over {world} ranks: frame {'identical' if ok else 'DIFFERS'}", flush=True)
+        print(f"{dist.get_backend()} gather over {world} ranks: frame {'identical' if ok else 'DIFFERS'}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1

@@ -35,6 +35,25 @@ def test_rccl_gather_equals_single_gpu_frame(world):
     assert codes == [0] * world, codes
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_path_rehearsed_on_one_gpu(world):
+    """The N-rank path with the ranks sharing GPU 0 and the gather staged through the host (gloo): every rank renders
+    its partition with the HIP library, sharding.FrameGather reassembles, rank 0 compares with its own whole frame."""
+    if _gpus() < 1:
+        pytest.skip("needs a GPU")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), LT_CHECK_DEVICES=",".join(["0"] * world), LT_CHECK_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "nccl_gather_check.py")], env=env))
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * world, codes
+
+
 def test_render_multi_on_real_devices():
     """lt_render_multi with one partition per real device (single process, no RCCL) == the one-device frame."""
     n = _gpus()
