@@ -83,9 +83,11 @@ def parse(argv=None):
                     help="one GPU plays rank --emulate-part of an N-GPU run: renders only that row partition (no gather); "
                          "tools/part_bench.py uses it to project the N-GPU frame time from one GPU")
     ap.add_argument("--emulate-part", type=int, default=0)
-    ap.add_argument("--balance", choices=["cyclic", "cost"], default="cyclic",
-                    help="row blocks -> ranks: block-cyclic (default), or cost-weighted from one untimed frame's step counts "
-                         "(sharding.balance_blocks: the rank that owns the longest ray gets less of the bulk)")
+    ap.add_argument("--balance", choices=["cyclic", "cost", "auto"], default="auto",
+                    help="row blocks -> ranks: block-cyclic, or cost-weighted from one untimed frame's step counts "
+                         "(sharding.balance_blocks: the rank that owns the longest ray gets less of the bulk). auto (default): "
+                         "cost-weighted for 8 or more ranks of the fixed-step Kerr frame -- where a rank's time is its longest "
+                         "ray plus its bulk (DESIGN.md 5.1: 3.87 against 4.13 ms per rank of 8) -- block-cyclic otherwise")
     ap.add_argument("--owner-file", default=None, help="(.npy, uint16) a row-block owner table to use as is (emulated ranks)")
     ap.add_argument("--chain-cost", type=float, default=137500.0,
                     help="--balance cost: lane-steps of bulk that take as long as one step of a lone ray (0.55 us / 4.0 ps)")
@@ -366,33 +368,44 @@ def main(argv=None):
     owner = None
     if args.owner_file:
         owner = np.load(args.owner_file).astype(np.uint16)
-    elif args.balance == "cost" and world > 1 and args.metric == "kerr":     # (an emulated rank takes --owner-file)
-        # one untimed frame on the default partition: per-row-block step totals and longest ray, all-gathered; every rank
-        # then computes the same owner table
+    elif (args.balance == "cost" or (args.balance == "auto" and world >= 8 and args.integrator == "rk4")) \
+            and world > 1 and args.metric == "kerr":     # (an emulated rank takes --owner-file)
+        # One untimed frame on the default partition: per-row-block step totals and longest ray, summed over the ranks;
+        # every rank then computes the same owner table.  Anything going wrong on any rank sends ALL ranks back to
+        # block-cyclic (the flag is reduced with the tables, so the ranks cannot disagree).
         nb = (size + rb - 1) // rb
-        o0 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
-                                 row_block=rb, n_parts=n_parts, part=part)
-        o0.stream = torch.cuda.current_stream(dev).cuda_stream
-        r0 = ltrace.local_rows(size, rb, n_parts, part)
-        d_steps0 = torch.empty((r0, size), dtype=torch.int32, device=dev)
-        ltrace.render_dev(cam, met, o0, d_steps=d_steps0.data_ptr())
-        torch.cuda.synchronize(dev)
-        st = d_steps0.to(torch.int64)
-        mine_blocks = torch.from_numpy(ltrace.global_rows(size, rb, n_parts, part)[::rb] // rb).to(dev)
-        per_row_sum, per_row_max = st.sum(dim=1), st.max(dim=1).values
-        pad = (-r0) % rb
-        if pad:
-            per_row_sum = torch.cat([per_row_sum, per_row_sum.new_zeros(pad)])
-            per_row_max = torch.cat([per_row_max, per_row_max.new_zeros(pad)])
         cost_t = torch.zeros(nb, dtype=torch.int64, device=dev)
         chain_t = torch.zeros(nb, dtype=torch.int64, device=dev)
-        cost_t[mine_blocks] = per_row_sum.view(-1, rb).sum(dim=1)
-        chain_t[mine_blocks] = per_row_max.view(-1, rb).max(dim=1).values
-        if world > 1:
-            all_reduce(cost_t, dist.ReduceOp.SUM)
-            all_reduce(chain_t, dist.ReduceOp.SUM)
-        owner = sharding.balance_blocks(cost_t.cpu().numpy(), chain_t.cpu().numpy(), n_parts, chain_cost=args.chain_cost)
-        del d_steps0, st
+        ok = 1
+        try:
+            o0 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
+                                     row_block=rb, n_parts=n_parts, part=part)
+            o0.stream = torch.cuda.current_stream(dev).cuda_stream
+            r0 = ltrace.local_rows(size, rb, n_parts, part)
+            d_steps0 = torch.empty((r0, size), dtype=torch.int32, device=dev)
+            ltrace.render_dev(cam, met, o0, d_steps=d_steps0.data_ptr())
+            torch.cuda.synchronize(dev)
+            st = d_steps0.to(torch.int64)
+            mine_blocks = torch.from_numpy(ltrace.global_rows(size, rb, n_parts, part)[::rb] // rb).to(dev)
+            per_row_sum, per_row_max = st.sum(dim=1), st.max(dim=1).values
+            pad = (-r0) % rb
+            if pad:
+                per_row_sum = torch.cat([per_row_sum, per_row_sum.new_zeros(pad)])
+                per_row_max = torch.cat([per_row_max, per_row_max.new_zeros(pad)])
+            cost_t[mine_blocks] = per_row_sum.view(-1, rb).sum(dim=1)
+            chain_t[mine_blocks] = per_row_max.view(-1, rb).max(dim=1).values
+            del d_steps0, st
+        except Exception as e:
+            print(f"bench.py: rank {rank}: cost pre-pass failed ({type(e).__name__}: {e}); block-cyclic partition", file=sys.stderr)
+            ok = 0
+        okt = torch.tensor([ok], dtype=torch.int64, device=dev)
+        all_reduce(okt, dist.ReduceOp.MIN)
+        all_reduce(cost_t, dist.ReduceOp.SUM)
+        all_reduce(chain_t, dist.ReduceOp.SUM)
+        if int(okt.item()) == 1:
+            owner = sharding.balance_blocks(cost_t.cpu().numpy(), chain_t.cpu().numpy(), n_parts, chain_cost=args.chain_cost)
+            if len(owner) != nb or int(owner.max()) >= n_parts:      # (a table every rank computes alike, or none)
+                owner = None
     if owner is not None:
         rows_max = max(len(ltrace.owned_rows(size, rb, owner, p)) for p in range(n_parts))
     else:
