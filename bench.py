@@ -19,7 +19,12 @@ and starts N copies of itself as child processes with RANK / LOCAL_RANK / WORLD_
 set, waits for them and exits with their worst code.  It never replaces a process that has
 initialised the GPU.  A rank whose process group does not have N members exits non-zero.
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Its contract fields are the headline region (fixed-step RK4, float32: the
+integrator BASELINE.json's north star names).  `production_path` is a second timed region of the same
+frame, same K and W, with the integrator the reference itself runs (`python image_lens.py --a 0.9` ->
+metrics.py:1128-1132 -> DP45 float64, metrics.py:419-567; the product's plugin default), with its own
+roofline and its own CPU baseline.  `projected_ranks` (N = 1): what each rank of a 2 / 4 / 8 GPU run
+renders, one rank at a time on this GPU -- a projection, labelled as one.
   roofline      the integrate kernel against the FP32 VALU ISSUE peak, from the work it executed:
                 wave-instructions per launch (rocprofv3 SQ_INSTS_VALU for this workload and this
                 build, profiles/valu_counts.json, scaled by the loop iterations the kernel counted
@@ -72,8 +77,11 @@ def parse(argv=None):
     ap.add_argument("--row-block", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the untimed extras (end-to-end host-pointer frame, longest-ray chain)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline leg")
+                    help="only the headline region: no pipelined region, no production-path region, no end-to-end host-pointer "
+                         "frame, no longest-ray chain, no per-rank projection (what the profiling scripts pass)")
+    ap.add_argument("--no-production-path", action="store_true",
+                    help="skip the second timed region (the same frame with the reference's production integrator, DP45 float64)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--background", action="store_true", help="image_lens workload: lens a synthetic background")
     ap.add_argument("--frames-in-flight", type=int, default=1,
                     help="1: frames strictly one after the other on one stream (the contract's per-launch roofline). "
@@ -85,9 +93,10 @@ def parse(argv=None):
     ap.add_argument("--emulate-part", type=int, default=0)
     ap.add_argument("--balance", choices=["cyclic", "cost", "auto"], default="auto",
                     help="row blocks -> ranks: block-cyclic, or cost-weighted from one untimed frame's step counts "
-                         "(sharding.balance_blocks: the rank that owns the longest ray gets less of the bulk). auto (default): "
-                         "cost-weighted for 8 or more ranks of the fixed-step Kerr frame -- where a rank's time is its longest "
-                         "ray plus its bulk (DESIGN.md 5.1: 3.87 against 4.13 ms per rank of 8) -- block-cyclic otherwise")
+                         "(sharding.balance_blocks: the rank that owns the longest ray gets less of the bulk; DESIGN.md 5.1: "
+                         "3.87 against 4.13 ms per rank of 8, emulated on one GPU). auto (default) IS block-cyclic: the "
+                         "cost-weighted table has never run over RCCL on real devices, so it is opt-in until a hardware run "
+                         "confirms the gain; the JSON line records which partition the timed region ran")
     ap.add_argument("--owner-file", default=None, help="(.npy, uint16) a row-block owner table to use as is (emulated ranks)")
     ap.add_argument("--chain-cost", type=float, default=137500.0,
                     help="--balance cost: lane-steps of bulk that take as long as one step of a lone ray (0.55 us / 4.0 ps)")
@@ -160,16 +169,17 @@ def usable_cpus():
     return n
 
 
-def cpu_baseline(args, fov):
+def cpu_baseline(args, fov, integrator):
     """Oracle (CPU port of the reference's tracer, float64, OpenMP), perf build, on a strided subsample of the
     benchmark frame: pixel (k*i, k*j) of the size^2 frame is pixel (i, j) of the (size/k)^2 frame of the same
-    camera.  One thread per usable CPU."""
+    camera.  One thread per usable CPU.  `integrator`: "rk4" (metrics.py:570-658) or "dp45" (metrics.py:419-567,
+    the reference's production path)."""
     cores = usable_cpus()
     from oracle import oracle
     oracle.set_num_threads(cores, perf_build=True)         # (torch initialised libgomp long ago: the environment is not read again)
     threads = oracle.lib_perf().lto_num_threads()
     kind = args.metric
-    kw = dict(integrator="rk4" if args.integrator == "rk4" else "dp45", perf_build=True)
+    kw = dict(integrator="rk4" if integrator == "rk4" else "dp45", perf_build=True)
     oracle.lookup(kind, 1.0, args.a, args.r_obs, 64, 64, fov, fov, **kw)       # compiles; spins the threads up
     t0 = time.perf_counter()
     oracle.lookup(kind, 1.0, args.a, args.r_obs, 256, 256, fov, fov, **kw)
@@ -185,7 +195,7 @@ def cpu_baseline(args, fov):
             "host_cpus_visible": os.cpu_count(),
             "kind": "port (perf build: gcc " + " ".join(oracle.PERF_FLAGS[:3]) + ", built on this host)",
             "sample": f"{n}x{n} rays = every {stride}th pixel (x and y) of the {args.size}x{args.size} frame, "
-                      f"oracle {args.integrator} float64 + OpenMP on {threads} threads (the job's CPU quota), {dt:.1f} s",
+                      f"oracle {kw['integrator']} float64 + OpenMP on {threads} threads (the job's CPU quota), {dt:.1f} s",
             "mean_rhs_evals_per_ray": round(float(r["evals"].mean()), 1)}
 
 
@@ -197,7 +207,7 @@ def end_to_end(ltrace, cam, met, args, np):
     import ctypes as C
     for name in ("pinned_dst_ms", "pageable_dst_ms"):
         if name == "pinned_dst_ms":
-            rgba = ltrace.pinned_empty((cam.height, cam.width, 4), np.uint8)
+            rgba = ltrace.pinned_empty((cam.height, cam.width, 4), np.uint8, strict=True)
         else:
             rgba = np.empty((cam.height, cam.width, 4), dtype=np.uint8)
             rgba[:] = 0                                      # touch the pages: a first-touch fault is not PCIe
@@ -342,6 +352,24 @@ def main(argv=None):
         if rccl_world != args.gpus:
             print(f"bench.py: the process group has {rccl_world} ranks, --gpus {args.gpus}", file=sys.stderr)
             return 2
+    # who this rank is: one line per rank on stderr, and (N > 1) every rank's device in the JSON line, so that a
+    # multi-GPU number can be checked against the devices it ran on
+    ident = {"rank": rank, "device_index": dev_index}
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        ident["name"] = props.name
+        ident["uuid"] = str(getattr(props, "uuid", ""))
+        ident["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if world > 1 and not staged else None
+    except Exception as e:                       # identification must not cost the run
+        ident["error"] = f"{type(e).__name__}: {e}"
+    print(f"bench.py: rank {rank}/{world} pid {os.getpid()} {ident}", file=sys.stderr, flush=True)
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len({(i or {}).get("uuid") or f"idx{(i or {}).get('device_index')}" for i in idents}) != world and not dev_map:
+            print("bench.py: two ranks report the same device", file=sys.stderr)
+            return 2
 
     def all_reduce(t, op):
         if not staged:
@@ -358,6 +386,11 @@ def main(argv=None):
             for o_, c_ in zip(out, co):
                 o_.copy_(c_)
 
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
     size = args.size
     fov = float(np.radians(40.0))
     cam = ltrace.Camera(size, size, fov, fov, 0.0, 0.0, args.r_obs, np.pi / 2)
@@ -365,14 +398,18 @@ def main(argv=None):
                         args.a if args.metric == "kerr" else 0.0)
     rb = args.row_block
     n_parts, part = (args.emulate_parts, args.emulate_part) if (args.emulate_parts and world == 1) else (world, rank)
-    owner = None
+    spin = args.a if args.metric == "kerr" else 0.0
+    bid = ltrace.build_id()
+    main_stream = torch.cuda.current_stream(dev)
+
+    # ---- row blocks -> ranks.  `auto` IS block-cyclic: the cost-weighted table (3.87 against 4.13 ms for the
+    # slowest rank of 8, emulated on one GPU) has never run over RCCL on real devices, so it stays opt-in (--balance cost)
+    # until a hardware run confirms it; and when asked for, any failure on any rank sends ALL ranks back to block-cyclic.
+    owner, balance_used = None, "cyclic"
     if args.owner_file:
         owner = np.load(args.owner_file).astype(np.uint16)
-    elif (args.balance == "cost" or (args.balance == "auto" and world >= 8 and args.integrator == "rk4")) \
-            and world > 1 and args.metric == "kerr":     # (an emulated rank takes --owner-file)
-        # One untimed frame on the default partition: per-row-block step totals and longest ray, summed over the ranks;
-        # every rank then computes the same owner table.  Anything going wrong on any rank sends ALL ranks back to
-        # block-cyclic (the flag is reduced with the tables, so the ranks cannot disagree).
+        balance_used = "owner-file"
+    elif args.balance == "cost" and world > 1 and args.metric == "kerr":     # (an emulated rank takes --owner-file)
         nb = (size + rb - 1) // rb
         cost_t = torch.zeros(nb, dtype=torch.int64, device=dev)
         chain_t = torch.zeros(nb, dtype=torch.int64, device=dev)
@@ -380,7 +417,7 @@ def main(argv=None):
         try:
             o0 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
                                      row_block=rb, n_parts=n_parts, part=part)
-            o0.stream = torch.cuda.current_stream(dev).cuda_stream
+            o0.stream = main_stream.cuda_stream
             r0 = ltrace.local_rows(size, rb, n_parts, part)
             d_steps0 = torch.empty((r0, size), dtype=torch.int32, device=dev)
             ltrace.render_dev(cam, met, o0, d_steps=d_steps0.data_ptr())
@@ -406,172 +443,190 @@ def main(argv=None):
             owner = sharding.balance_blocks(cost_t.cpu().numpy(), chain_t.cpu().numpy(), n_parts, chain_cost=args.chain_cost)
             if len(owner) != nb or int(owner.max()) >= n_parts:      # (a table every rank computes alike, or none)
                 owner = None
+        if owner is not None:
+            # one untimed frame through the table-mode render on every rank before it is trusted (the gather that follows
+            # is the same collective either way); a rank that fails takes every rank back to block-cyclic
+            ok = 1
+            try:
+                o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
+                                         row_block=rb, n_parts=n_parts, part=part, block_owner=owner)
+                o1.stream = main_stream.cuda_stream
+                r1 = len(ltrace.owned_rows(size, rb, owner, part))
+                probe = torch.empty((max(r1, 1), size, 4), dtype=torch.uint8, device=dev)
+                ltrace.render_dev(cam, met, o1, d_rgba=probe.data_ptr())
+                torch.cuda.synchronize(dev)
+                del probe
+            except Exception as e:
+                print(f"bench.py: rank {rank}: table-mode render failed ({type(e).__name__}: {e}); block-cyclic partition", file=sys.stderr)
+                ok = 0
+            okt = torch.tensor([ok], dtype=torch.int64, device=dev)
+            all_reduce(okt, dist.ReduceOp.MIN)
+            if int(okt.item()) != 1:
+                owner = None
+        balance_used = "cost" if owner is not None else "cyclic (cost-weighted table unavailable: fell back)"
     if owner is not None:
         rows_max = max(len(ltrace.owned_rows(size, rb, owner, p)) for p in range(n_parts))
     else:
         rows_max = max(ltrace.local_rows(size, rb, n_parts, p) for p in range(n_parts))
 
-    # device buffers (torch owns the memory; the library only sees raw pointers); one set per frame in flight
-    F = max(1, args.frames_in_flight)
     d_stats = torch.zeros(ltrace.STAT_WORDS, dtype=torch.int64, device=dev)
     d_bg = None
     if args.background:
         g = torch.Generator(device="cpu").manual_seed(0)
         d_bg = (torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8).to(torch.float32) / 255.0).to(dev)
     torch.cuda.synchronize(dev)
-    def make_sets(nf):
-        out = []
-        for f in range(nf):
-            st = torch.cuda.current_stream(dev) if nf == 1 else torch.cuda.Stream(dev)
-            o = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule,
-                                    row_block=rb, n_parts=n_parts, part=part, timing=1, block_owner=owner,
-                                    bg_sampling=ltrace.BG_LDS_TILES if args.bg_sampling == "lds" else ltrace.BG_GLOBAL)
-            o.stream = st.cuda_stream
-            fg = (sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank, owner=owner) if n_parts == world else
-                  sharding.FrameGather(rows_max, size, 4, torch.uint8, dev, rows_max, 1, 0))          # emulated rank: no gather
-            out.append(dict(stream=st, opts=o, fg=fg,   # RGBA8 framebuffer
-                            fa=torch.empty((rows_max, size), dtype=torch.float32, device=dev),
-                            w=torch.empty((rows_max, size), dtype=torch.int16, device=dev)))
-        return out
 
-    sets = make_sets(F)
-    stream = sets[0]["stream"]
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(args.steps, 1))]   # frame start / rendered / gathered
+    def workload_name(integ):
+        w = f"{args.metric}_a{spin}_shadow_{size}x{size}_r{args.r_obs:g}_{integ}"
+        return w + ("_lensed_background" if args.background else "")
 
-    def step(i=None, k=0, sets_=None):
-        ss = sets_ or sets
-        b = ss[k % len(ss)]
-        st = b["stream"]
-        with torch.cuda.stream(st):
-            if i is not None:
-                ev[3 * i].record(st)
-            ltrace.render_dev(cam, met, b["opts"], d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
-                              d_fa=b["fa"].data_ptr(), d_w=b["w"].data_ptr(), d_rgba=b["fg"].local.data_ptr(),
-                              d_stats=d_stats.data_ptr())
-            if i is not None:
-                ev[3 * i + 1].record(st)
-            full = b["fg"].gather(st.cuda_stream)   # N > 1: RCCL gather to rank 0 + row un-permute there
-            if i is not None:
-                ev[3 * i + 2].record(st)
-        return full
+    # --------------------------------------------------------------------------------------------
+    # one timed region: W warm-up frames, then K frames between barrier + synchronize on both sides
+    # --------------------------------------------------------------------------------------------
+    def run_region(integ, prec, K, Wu, F, pipelined_extra):
+        def make_sets(nf):
+            out = []
+            for f in range(nf):
+                st = main_stream if nf == 1 else torch.cuda.Stream(dev)
+                o = ltrace.default_opts(integrator=integ, precision=prec, schedule=args.schedule,
+                                        row_block=rb, n_parts=n_parts, part=part, timing=1, block_owner=owner,
+                                        bg_sampling=ltrace.BG_LDS_TILES if args.bg_sampling == "lds" else ltrace.BG_GLOBAL)
+                o.stream = st.cuda_stream
+                fg = (sharding.FrameGather(size, size, 4, torch.uint8, dev, rb, world, rank, owner=owner) if n_parts == world else
+                      sharding.FrameGather(rows_max, size, 4, torch.uint8, dev, rows_max, 1, 0))          # emulated rank: no gather
+                out.append(dict(stream=st, opts=o, fg=fg,   # RGBA8 framebuffer
+                                fa=torch.empty((rows_max, size), dtype=torch.float32, device=dev),
+                                w=torch.empty((rows_max, size), dtype=torch.int16, device=dev)))
+            return out
 
-    def fence():
+        def drop_sets(ss):
+            # a stream made for a region owns ray records inside the library (0.8 GB at 4096^2 float32): give them back
+            torch.cuda.synchronize(dev)
+            for b in ss:
+                if b["stream"] is not main_stream:
+                    ltrace.release_stream(b["stream"].cuda_stream)
+
+        sets = make_sets(F)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(K, 1))]   # frame start / rendered / gathered
+
+        def step(i, k, ss):
+            b = ss[k % len(ss)]
+            st = b["stream"]
+            with torch.cuda.stream(st):
+                if i is not None:
+                    ev[3 * i].record(st)
+                ltrace.render_dev(cam, met, b["opts"], d_bg=d_bg.data_ptr() if d_bg is not None else 0, bg_channels=3,
+                                  d_fa=b["fa"].data_ptr(), d_w=b["w"].data_ptr(), d_rgba=b["fg"].local_view().data_ptr(),
+                                  d_stats=d_stats.data_ptr())
+                if i is not None:
+                    ev[3 * i + 1].record(st)
+                full = b["fg"].gather(st.cuda_stream)   # N > 1: RCCL exchange to rank 0 + row un-permute there
+                if i is not None:
+                    ev[3 * i + 2].record(st)
+            return full
+
+        for j in range(Wu):
+            step(None, j, sets)
+        fence()
+        ltrace.timing_collect()            # drop warm-up events
+        d_stats.zero_()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(K):
+            step(i, i, sets)
+        fence()
+        elapsed = time.perf_counter() - t0
+        tm = ltrace.timing_collect()
+
+        steps = max(K, 1)
+        render_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(K)) / steps
+        gather_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(K)) / steps
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        counters = d_stats.clone()
+        mine = torch.tensor([tm["prologue_ms"] / steps, tm["integrate_ms"] / steps, tm["epilogue_ms"] / steps,
+                             render_ms, gather_ms], dtype=torch.float64, device=dev)
+        per_rank = [mine]
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            all_reduce(t, dist.ReduceOp.MAX)
+            per_rank = [torch.zeros_like(mine) for _ in range(world)]
+            all_gather(per_rank, mine)
+        elapsed = float(t.item())
+        my = [int(x) for x in counters.tolist()]
+        if world > 1:
+            all_reduce(counters, dist.ReduceOp.SUM)
+        c = [int(x) for x in counters.tolist()]
+        per_rank = [[float(x) for x in r.tolist()] for r in per_rank]
+        # counters of every rank's integrate kernel (the slowest rank's launch is the one priced)
+        mine_k = torch.tensor([my[ltrace.STAT_WAVE_ITERS], my[ltrace.STAT_WAVES], my[ltrace.STAT_CLK_CYCLES],
+                               my[ltrace.STAT_CLK_TICKS], my[ltrace.STAT_STEPS], my[ltrace.STAT_RAYS]], dtype=torch.int64, device=dev)
+        all_k = [mine_k]
+        if world > 1:
+            all_k = [torch.zeros_like(mine_k) for _ in range(world)]
+            all_gather(all_k, mine_k)
+        all_k = [[int(x) for x in k.tolist()] for k in all_k]
+        rays_per_frame = c[ltrace.STAT_RAYS] // steps
+        R = dict(integrator=integ, precision=prec, steps=K, warmup=Wu, frames_in_flight=F, elapsed=elapsed,
+                 ms_per_step=elapsed / steps * 1e3, rays_per_frame=rays_per_frame,
+                 value=rays_per_frame / (elapsed / steps) / 1e6, counters=c, per_rank=per_rank, all_k=all_k,
+                 slow=max(range(world), key=lambda r: per_rank[r][1]), pipelined=None)
 
-    for j in range(args.warmup):
-        step(None, j)
-    fence()
-    ltrace.timing_collect()            # drop warm-up events
-    d_stats.zero_()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    tm = ltrace.timing_collect()
+        # second region, same K and W, frames pipelined (every rank takes part: the exchange is collective)
+        if F == 1 and pipelined_extra > 1:
+            psets = None
+            try:
+                psets = make_sets(pipelined_extra)
+                for j in range(max(Wu, pipelined_extra)):
+                    step(None, j, psets)
+                fence()
+                t0 = time.perf_counter()
+                for i in range(K):
+                    step(None, i, psets)
+                fence()
+                tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                if world > 1:
+                    all_reduce(tp, dist.ReduceOp.MAX)
+                ltrace.timing_collect()
+                pel = float(tp.item())
+                R["pipelined"] = {"frames_in_flight": pipelined_extra, "value": round(rays_per_frame / (pel / steps) / 1e6, 2), "unit": "Mrays/s",
+                                  "ms_per_step": round(pel / steps * 1e3, 4),
+                                  "what": f"the same {K} frames after the same warm-up, frame i on stream i % {pipelined_extra} with its own buffers: "
+                                          "the tail of a frame (a few lone wavefronts finishing its longest rays) overlaps the bulk of the next. "
+                                          "Throughput of a frame SEQUENCE; `value` above is frames strictly one after the other"}
+            except Exception as e:      # the headline line must not depend on the extra region
+                R["pipelined"] = {"error": f"{type(e).__name__}: {e}"}
+            if psets:
+                drop_sets(psets)
+        drop_sets(sets)
+        return R
 
-    steps = max(args.steps, 1)
-    render_ms = sum(ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(args.steps)) / steps
-    gather_ms = sum(ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(args.steps)) / steps
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    counters = d_stats.clone()
-    mine = torch.tensor([tm["prologue_ms"] / steps, tm["integrate_ms"] / steps, tm["epilogue_ms"] / steps,
-                         render_ms, gather_ms], dtype=torch.float64, device=dev)
-    per_rank = [mine]
-    if world > 1:
-        all_reduce(t, dist.ReduceOp.MAX)
-        per_rank = [torch.zeros_like(mine) for _ in range(world)]
-        all_gather(per_rank, mine)
-    elapsed = float(t.item())
-    my = [int(x) for x in counters.tolist()]
-    if world > 1:
-        all_reduce(counters, dist.ReduceOp.SUM)
-    c = [int(x) for x in counters.tolist()]
-    per_rank = [[float(x) for x in r.tolist()] for r in per_rank]
-    slow = max(range(world), key=lambda r: per_rank[r][1])        # the rank with the longest integrate kernel
-    # counters of the slowest rank (its kernel is the one priced): exchange wave_iters / clock words
-    mine_k = torch.tensor([my[ltrace.STAT_WAVE_ITERS], my[ltrace.STAT_WAVES], my[ltrace.STAT_CLK_CYCLES],
-                           my[ltrace.STAT_CLK_TICKS], my[ltrace.STAT_STEPS], my[ltrace.STAT_RAYS]], dtype=torch.int64, device=dev)
-    all_k = [mine_k]
-    if world > 1:
-        all_k = [torch.zeros_like(mine_k) for _ in range(world)]
-        all_gather(all_k, mine_k)
-    all_k = [[int(x) for x in k.tolist()] for k in all_k]
-
-    rays_per_frame = c[ltrace.STAT_RAYS] // steps
-    rk_steps = c[ltrace.STAT_STEPS] / steps
-    ms_per_step = elapsed / steps * 1e3
-    value = rays_per_frame / (elapsed / steps) / 1e6
-
-    # second region, same K and W, frames pipelined 3 deep (every rank takes part: the gather is collective)
-    pipelined = None
-    if F == 1 and not args.no_extras and args.pipelined_extra > 1:
-        try:
-            psets = make_sets(args.pipelined_extra)
-            for j in range(max(args.warmup, args.pipelined_extra)):
-                step(None, j, psets)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                step(None, i, psets)
-            fence()
-            tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-            if world > 1:
-                all_reduce(tp, dist.ReduceOp.MAX)
-            ltrace.timing_collect()
-            pel = float(tp.item())
-            pipelined = {"frames_in_flight": args.pipelined_extra, "value": round(rays_per_frame / (pel / steps) / 1e6, 2), "unit": "Mrays/s",
-                         "ms_per_step": round(pel / steps * 1e3, 4),
-                         "what": f"the same {args.steps} frames after the same warm-up, frame i on stream i % {args.pipelined_extra} with its own buffers: "
-                                 "the tail of a frame (a few lone wavefronts finishing its longest rays) overlaps the bulk of the next. "
-                                 "Throughput of a frame SEQUENCE; `value` above is frames strictly one after the other"}
-            del psets
-        except Exception as e:      # the headline line must not depend on the extra region
-            pipelined = {"error": f"{type(e).__name__}: {e}"}
-
-    # untimed extras (rank 0, one GPU): longest-ray chain and the host-pointer end-to-end frame
-    chain = e2e = None
-    if rank == 0 and world == 1 and n_parts == 1 and not args.no_extras and args.metric == "kerr":
-        d_steps = torch.empty((size, size), dtype=torch.int32, device=dev)
-        o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
-        o1.stream = stream.cuda_stream
-        ltrace.render_dev(cam, met, o1, d_steps=d_steps.data_ptr())
-        torch.cuda.synchronize(dev)
-        chain = longest_chain(ltrace, cam, met, args, d_steps.cpu().numpy(), np)
-        del d_steps
-        if not args.background:
-            e2e = end_to_end(ltrace, cam, met, args, np)
-
-    if rank == 0:
-        spin = args.a if args.metric == "kerr" else 0.0
-        workload = f"{args.metric}_a{spin}_shadow_{size}x{size}_r{args.r_obs:g}_{args.integrator}"
-        if args.background:
-            workload += "_lensed_background"
-        kernel = (f"k_kerr_{args.schedule}<{args.integrator}>" if args.metric == "kerr" else "k_schw_rk4_direct")
-        key = f"{workload}|f{args.precision}|{args.schedule}|parts{n_parts}"
+    # --------------------------------------------------------------------------------------------
+    # the integrate kernel of a region against its VALU-issue roofline (executed work, PMC-counted)
+    # --------------------------------------------------------------------------------------------
+    def roofline_of(R):
+        integ, prec, steps = R["integrator"], R["precision"], max(R["steps"], 1)
+        workload = workload_name(integ)
+        kernel = (f"k_kerr_{args.schedule}<{integ}>" if args.metric == "kerr" else "k_schw_rk4_direct")
+        key = f"{workload}|f{prec}|{args.schedule}|parts{n_parts}"
         if n_parts != world:
             key += f"|part{part}"
-        bid = ltrace.build_id()
-        # --- executed work of the priced launch (the slowest rank's integrate kernel)
-        k_iters, k_waves, k_cyc, k_ticks, k_steps, k_rays = all_k[slow]
-        integ_ms = per_rank[slow][1]
+        slow = R["slow"]
+        k_iters, k_waves, k_cyc, k_ticks, k_steps, k_rays = R["all_k"][slow]
+        integ_ms = R["per_rank"][slow][1]
         iters_per_launch = k_iters / steps
         vc = load_profile_json("valu_counts.json")
-        rec = (vc.get("workloads") or {}).get(key) or (vc.get("workloads") or {}).get(f"{workload}|f{args.precision}|{args.schedule}|parts1")
+        wl = vc.get("workloads") or {}
+        rec = wl.get(key) or wl.get(f"{workload}|f{prec}|{args.schedule}|parts1")
         valu_src, valu_per_iter = None, None
         if rec and rec.get("wave_iters"):
             valu_per_iter = rec["valu_insts"] / rec["wave_iters"]
-            fresh = vc.get("build_id") == bid
+            rec_bid = rec.get("build_id") or vc.get("build_id")
             valu_src = (f"{rec.get('source', 'profiles/valu_counts.json')}: SQ_INSTS_VALU {rec['valu_insts']} / wave_iters "
-                        f"{rec['wave_iters']} per launch" + ("" if fresh else f"; STALE: measured on build {vc.get('build_id')}, this is {bid}"))
-        peak = PEAK_FP32_VALU_TFLOPS if args.precision == 32 else PEAK_FP64_VALU_TFLOPS
-        cyc = CYCLES_PER_VALU[args.precision]
+                        f"{rec['wave_iters']} per launch" + ("" if rec_bid == bid else f"; STALE: measured on build {rec_bid}, this is {bid}"))
+        peak = PEAK_FP32_VALU_TFLOPS if prec == 32 else PEAK_FP64_VALU_TFLOPS
+        cyc = CYCLES_PER_VALU[prec]
         clock_mhz = k_cyc / k_ticks * 100.0 if k_ticks else None
-        roof = {"bound": "valu_issue_fp32" if args.precision == 32 else "valu_issue_fp64", "kernel": kernel,
-                "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
+        roof = {"bound": "valu_issue_fp32" if prec == 32 else "valu_issue_fp64", "kernel": kernel,
+                "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "frac_at_held_clock": None, "traffic": None,
                 "avg_launch_ms": round(integ_ms, 4), "priced_rank": slow}
         if valu_per_iter and integ_ms > 0:
             valu = valu_per_iter * iters_per_launch               # wave-instructions this launch issued
@@ -580,72 +635,162 @@ def main(argv=None):
             lane_flops = 64 * 2                                   # one FMA per lane per issue slot
             roof["achieved"] = round(slots_per_s * lane_flops / 1e12, 2)   # FMA-equivalent: every issue slot priced as one FMA
             roof["frac"] = round(slots_per_s / peak_slots, 4)
+            roof["frac_at_held_clock"] = round(slots_per_s / (N_SIMD * clock_mhz * 1e6 / cyc), 4) if clock_mhz else None
             # the same over the whole timed region (prologue, epilogue, gaps and -- with frames in flight -- overlap
             # included): wave-instructions the integrate kernels of this rank issued / (wall time x issue peak)
-            roof["region_issue_frac"] = round(valu * steps / elapsed / peak_slots, 4)
-            if F > 1:
-                roof["note"] = (f"{F} frames in flight: launches of consecutive frames overlap, so avg_launch_ms (HIP events around "
+            roof["region_issue_frac"] = round(valu * steps / R["elapsed"] / peak_slots, 4)
+            if R["frames_in_flight"] > 1:
+                roof["note"] = (f"{R['frames_in_flight']} frames in flight: launches of consecutive frames overlap, so avg_launch_ms (HIP events around "
                                 "each launch) includes time shared with the neighbouring frame and `frac` understates; "
                                 "`region_issue_frac` is the chip-level figure for this mode")
             roof["executed"] = {"valu_wave_insts_per_launch": int(valu), "wave_iters_per_launch": int(iters_per_launch),
                                 "valu_per_wave_iter": round(valu_per_iter, 2), "waves": int(k_waves / steps),
                                 "issue_cycles_per_inst": cyc, "source": valu_src,
                                 "clock_mhz_held": round(clock_mhz, 1) if clock_mhz else None,
-                                "frac_at_held_clock": round(slots_per_s / (N_SIMD * clock_mhz * 1e6 / cyc), 4) if clock_mhz else None}
+                                "frac_at_held_clock": roof["frac_at_held_clock"]}
         else:
             roof["executed"] = {"wave_iters_per_launch": int(iters_per_launch), "source": "no VALU count for this workload under profiles/ "
-                                "(tools/refresh_profiles.sh); frac left null rather than guessed"}
+                                "(tools/pmc_counts.py); frac left null rather than guessed"}
         # --- the reference's as-written count, for the record
         slow_steps, slow_rays = k_steps / steps, k_rays / steps
         if args.metric == "kerr":
-            flops = (slow_steps * F_DP45_ATTEMPT + slow_rays * (F_KERR_FIXED + 188)) if args.integrator != "rk4" else \
+            flops = (slow_steps * F_DP45_ATTEMPT + slow_rays * (F_KERR_FIXED + 188)) if integ != "rk4" else \
                     (slow_steps * F_RK4_STEP + slow_rays * F_KERR_FIXED)
         else:
             flops = slow_steps * F_SCHW_STEP + slow_rays * F_SCHW_FIXED
         aw = flops / (integ_ms * 1e-3) / 1e12 if integ_ms > 0 else 0.0
         roof["algorithmic_as_written"] = {"flops_per_launch": int(flops), "tflops": round(aw, 2), "of_peak": round(aw / peak, 4),
-                                          "note": "the reference's un-simplified op count (832 per RK4 step); the kernel executes "
-                                                  "about a third of it, so this can exceed 1 and is not a roofline fraction"}
+                                          "note": "the reference's un-simplified op count (832 per RK4 step, 1448 per DP45 attempt); the kernel "
+                                                  "executes a fraction of it, so this can exceed 1 and is not a roofline fraction"}
         # --- HBM traffic of the integrate kernel: only from a PMC pass of THIS build on THIS workload
         tr = load_profile_json("hbm_traffic.json")
         trec = (tr.get("workloads") or {}).get(key)
-        if trec and tr.get("build_id") == bid:
+        if trec and (trec.get("build_id") or tr.get("build_id")) == bid:
             roof["traffic"] = trec["bytes_per_launch"]
             roof["traffic_source"] = trec.get("source")
-        roof["algorithmic_bytes_per_launch"] = int(k_waves / steps * 64 * 12 * (4 if args.precision == 32 else 8))
-        roof["other_kernels_ms"] = {"prologue": round(per_rank[slow][0], 4), "epilogue": round(per_rank[slow][2], 4)}
+        roof["algorithmic_bytes_per_launch"] = int(k_waves / steps * 64 * 12 * (4 if prec == 32 else 8))
+        roof["other_kernels_ms"] = {"prologue": round(R["per_rank"][slow][0], 4), "epilogue": round(R["per_rank"][slow][2], 4)}
+        return roof, workload, key
+
+    # what ONE rank of an n-GPU run renders, each rank in turn on this one GPU under benchmark conditions
+    def projected_ranks(integ, prec, frames=4):
+        res = {}
+        for n in (2, 4, 8):
+            per = []
+            for p in range(n):
+                rows = ltrace.local_rows(size, rb, n, p)
+                rgba = torch.empty((max(rows, 1), size, 4), dtype=torch.uint8, device=dev)
+                o = ltrace.default_opts(integrator=integ, precision=prec, schedule=args.schedule, row_block=rb, n_parts=n, part=p)
+                o.stream = main_stream.cuda_stream
+                for _ in range(2):
+                    ltrace.render_dev(cam, met, o, d_rgba=rgba.data_ptr())
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(frames):
+                    ltrace.render_dev(cam, met, o, d_rgba=rgba.data_ptr())
+                torch.cuda.synchronize(dev)
+                per.append((time.perf_counter() - t0) / frames * 1e3)
+                del rgba
+            worst = max(per)
+            res[str(n)] = {"frame_ms_per_rank": [round(x, 3) for x in per], "slowest_rank_ms": round(worst, 3),
+                           "mrays_per_s_before_gather": round(size * size / worst / 1e3, 1)}
+        res["what"] = (f"PROJECTION from one GPU, not a multi-GPU measurement: rank p of n (block-cyclic {rb}-row blocks) renders its rows "
+                       f"alone on this GPU, {frames} frames back to back after 2 warm-up frames; an n-GPU frame takes at least the slowest "
+                       "rank's time plus the gather (4 MiB x rows / 1024 per peer over one xGMI link each)")
+        return res
+
+    F = max(1, args.frames_in_flight)
+    extras = not args.no_extras
+    H = run_region(args.integrator, args.precision, args.steps, args.warmup, F, args.pipelined_extra if extras else 0)
+
+    # ---- the reference's production path (metrics.py:419-567 via :1128-1132: DP45, float64), same frame, same K and W.
+    # It is what `python image_lens.py --a 0.9` integrates with and what the plugin surface defaults to (metrics.py of
+    # the product: dp45_exact); the headline above is the fixed-step float32 integrator BASELINE.json's north star names.
+    P = None
+    want_prod = (extras and not args.no_production_path and args.metric == "kerr" and args.integrator == "rk4"
+                 and not args.background and n_parts == world)
+    if want_prod:
+        P = run_region("dp45_exact", 64, args.steps, min(args.warmup, 3), 1, 0)
+
+    # untimed extras (rank 0, one GPU): longest-ray chain, host-pointer end-to-end frame, per-rank projection
+    chain = e2e = proj = None
+    if rank == 0 and world == 1 and n_parts == 1 and extras and args.metric == "kerr":
+        d_steps = torch.empty((size, size), dtype=torch.int32, device=dev)
+        o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
+        o1.stream = main_stream.cuda_stream
+        ltrace.render_dev(cam, met, o1, d_steps=d_steps.data_ptr())
+        torch.cuda.synchronize(dev)
+        chain = longest_chain(ltrace, cam, met, args, d_steps.cpu().numpy(), np)
+        del d_steps
+        if not args.background:
+            e2e = end_to_end(ltrace, cam, met, args, np)
+            try:
+                proj = {args.integrator: projected_ranks(args.integrator, args.precision)}
+                if P is not None:
+                    proj["dp45_exact"] = projected_ranks("dp45_exact", 64)
+            except Exception as e:
+                proj = {"error": f"{type(e).__name__}: {e}"}
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        roof, workload, key = roofline_of(H)
+        c = H["counters"]
         out = {
-            "metric": "Mrays/s", "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "metric": "Mrays/s", "value": round(H["value"], 2), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(H["ms_per_step"], 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == 32 else "f64", "data": "synthetic",
             "config": {"workload": workload,
-                       "rays_per_frame": rays_per_frame, "schedule": args.schedule, "build_id": bid, "profile_key": key,
+                       "rays_per_frame": H["rays_per_frame"], "schedule": args.schedule, "build_id": bid, "profile_key": key,
                        "row_partition": (f"block-cyclic {rb} rows x {n_parts}" if owner is None else
                                          f"cost-weighted {rb}-row blocks x {n_parts} (rows per rank "
                                          f"{[len(ltrace.owned_rows(size, rb, owner, p)) for p in range(n_parts)]})") + (f" (emulated rank {part} on one GPU)" if n_parts != world else ""),
-                       "gather": ("rccl" if not staged else "gloo, staged through the host (rehearsal)") if world > 1 else "none",
+                       "balance": {"requested": args.balance, "used": balance_used},
+                       "gather": ("rccl send/recv to rank 0, exact partition sizes" if not staged else "gloo, staged through the host (rehearsal)") if world > 1 else "none",
                        **({"rehearsal_devices": dev_map} if dev_map else {}),
                        "frames_in_flight": F,
-                       "mean_rk4_steps_per_ray": round(rk_steps / max(rays_per_frame, 1), 2),
+                       "mean_rk4_steps_per_ray": round(c[ltrace.STAT_STEPS] / steps / max(H["rays_per_frame"], 1), 2),
                        "escaped": c[ltrace.STAT_ESCAPED] // steps, "captured": c[ltrace.STAT_CAPTURED] // steps,
                        "invalid": c[ltrace.STAT_INVALID] // steps,
                        **({"bg_sampling": args.bg_sampling, "bg_groups_lds": c[ltrace.STAT_BG_TILES_LDS] // steps,
                            "bg_groups_global": c[ltrace.STAT_BG_TILES_GLOBAL] // steps} if args.background else {})},
             "roofline": roof,
             "ranks": {"rccl_world": rccl_world,
-                      "integrate_ms": [round(r[1], 3) for r in per_rank],
-                      "render_ms": [round(r[3], 3) for r in per_rank],
-                      "gather_ms": [round(r[4], 3) for r in per_rank]},
+                      "integrate_ms": [round(r[1], 3) for r in H["per_rank"]],
+                      "render_ms": [round(r[3], 3) for r in H["per_rank"]],
+                      "gather_ms": [round(r[4], 3) for r in H["per_rank"]],
+                      "devices": idents},
         }
-        if pipelined:
-            out["pipelined"] = pipelined
+        if H["pipelined"]:
+            out["pipelined"] = H["pipelined"]
         if chain:
             out["chain_floor"] = chain
         if e2e:
             out["end_to_end_ms"] = e2e
+        if proj:
+            out["projected_ranks"] = proj
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, fov)
+            out["cpu_baseline"] = cpu_baseline(args, fov, args.integrator)
+        if P is not None:
+            proof, pworkload, pkey = roofline_of(P)
+            pc = P["counters"]
+            psteps = max(P["steps"], 1)
+            prod = {"what": "the same frame with the reference's production integrator (DP45 rtol 1e-8 / atol 1e-10, float64, "
+                            "metrics.py:419-567; step controller evaluated in float64 as written there) -- the plugin default",
+                    "metric": "Mrays/s", "value": round(P["value"], 2), "unit": "Mrays/s", "dtype": "f64",
+                    "steps": P["steps"], "warmup": P["warmup"], "ms_per_step": round(P["ms_per_step"], 4),
+                    "config": {"workload": pworkload, "profile_key": pkey, "rays_per_frame": P["rays_per_frame"],
+                               "mean_dp45_attempts_per_ray": round(pc[ltrace.STAT_STEPS] / psteps / max(P["rays_per_frame"], 1), 2),
+                               "mean_rhs_evals_per_ray": round(pc[ltrace.STAT_RHS_EVALS] / psteps / max(P["rays_per_frame"], 1), 1),
+                               "escaped": pc[ltrace.STAT_ESCAPED] // psteps, "captured": pc[ltrace.STAT_CAPTURED] // psteps,
+                               "invalid": pc[ltrace.STAT_INVALID] // psteps},
+                    "roofline": proof,
+                    "ranks": {"integrate_ms": [round(r[1], 3) for r in P["per_rank"]],
+                              "render_ms": [round(r[3], 3) for r in P["per_rank"]],
+                              "gather_ms": [round(r[4], 3) for r in P["per_rank"]]}}
+            if not args.no_cpu_baseline and world == 1:
+                prod["cpu_baseline"] = cpu_baseline(args, fov, "dp45")
+            out["production_path"] = prod
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -38,9 +38,11 @@ extern "C" {
  * Schwarzschild always uses its orbit-equation RK4, metrics.py:49-117. */
 #define LT_INTEGRATOR_DP45 0
 #define LT_INTEGRATOR_RK4 1
-#define LT_INTEGRATOR_DP45_EXACT 2 /* DP45 with the step-size controller evaluated in float64 exactly as metrics.py:506-522,
-                                      :560-564 writes it (LT_INTEGRATOR_DP45 evaluates it in float32, free of divisions and
-                                      pow): the reference's accept / reject sequence, at a measured cost */
+#define LT_INTEGRATOR_DP45_EXACT 2 /* DP45 with the step-size controller evaluated in float64, operation by operation as
+                                      metrics.py:506-522, :560-564 write it (LT_INTEGRATOR_DP45 evaluates it in float32, free
+                                      of divisions and pow).  Divisions and the power are ~1-ulp reciprocal / Newton forms, not
+                                      IEEE library calls: an accept / reject decision can differ from the reference's only
+                                      when err_norm is within a few ulp of 1 (measured: no golden ray) */
 
 /* ray -> lane scheduling of the integrate kernel */
 #define LT_SCHED_DIRECT 0 /* one work-item per ray, one 8x8 pixel tile per wavefront        */
@@ -243,6 +245,13 @@ int lt_shade(const lt_camera *cam, int32_t loop_around, const float *bg, int32_t
 int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t height, int32_t width,
                         int32_t elem_bytes, int32_t row_block, int32_t n_parts, int32_t part,
                         void *stream);
+
+/* The same for ANY assignment of rows (e.g. the frame as rank 0 received it, partition after partition, under a
+ * row-block -> rank table): d_rows holds n_rows rows of row_bytes bytes, source row i goes to row d_row_index[i] of
+ * d_full (height rows).  d_row_index is a DEVICE array of n_rows int64; entries outside [0, height) are skipped.
+ * One launch per 65535 rows, asynchronous on `stream`. */
+int lt_scatter_rows_indexed_dev(const void *d_rows, void *d_full, const int64_t *d_row_index, int64_t n_rows,
+                                int64_t height, int64_t row_bytes, void *stream);
 
 /* ---- batched dense trajectories ------------------------------------------------------------- *
  * Replaces geodesic_tracer.integrate_geodesic (geodesic_tracer.py:22-71) -- solve_ivp(RK45) on     *

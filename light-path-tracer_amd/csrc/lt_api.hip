@@ -942,11 +942,24 @@ extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, co
     const size_t n_full = (size_t)W * H;
     struct Part { hipStream_t s; StreamSlot *sl; char *base; int64_t rows; size_t o_stats, o_fa, o_w, o_st, o_steps, o_rgb, o_rgba; };
     std::vector<Part> parts((size_t)n_gpus);
+    std::vector<lt_stats> each((size_t)n_gpus); // destination of asynchronous copies: must outlive the drain below
+    // Any return before the end leaves kernels and device-to-host copies of other partitions in flight, writing the
+    // caller's arrays and `each`: drain every stream that was handed work before the frame (or the error) is returned.
+    struct Drain {
+        std::vector<std::pair<int, hipStream_t>> used;
+        bool done = false;
+        ~Drain()
+        {
+            if (done) return;
+            for (auto &u : used) { (void)hipSetDevice(u.first); (void)hipStreamSynchronize(u.second); }
+        }
+    } drain;
     // 1. launch every partition (asynchronous): all devices compute at the same time
     for (int p = 0; p < n_gpus; ++p) {
         Part &P = parts[(size_t)p];
         HIP_TRY(hipSetDevice(dev[(size_t)p]));
         if ((rc = multi_stream(dev[(size_t)p], p, &P.s))) return rc;
+        drain.used.push_back({dev[(size_t)p], P.s});
         if ((rc = get_slot(P.s, &P.sl))) return rc;
         P.rows = lt_local_rows(H, o.row_block, n_gpus, p);
         size_t n = (size_t)P.rows * W;
@@ -978,7 +991,6 @@ extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, co
     // 2. every device copies its row blocks to their place in the caller's full-frame arrays
     lt_stats total;
     memset(&total, 0, sizeof(total));
-    std::vector<lt_stats> each((size_t)n_gpus);
     for (int p = 0; p < n_gpus; ++p) {
         Part &P = parts[(size_t)p];
         HIP_TRY(hipSetDevice(dev[(size_t)p]));
@@ -1015,6 +1027,7 @@ extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, co
             if (ms[2] > total.epilogue_ms) total.epilogue_ms = ms[2];
         }
     }
+    drain.done = true; // every stream was synchronised above
     if (stats) *stats = total;
     return LT_OK;
 }
@@ -1148,6 +1161,27 @@ extern "C" int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t hei
     dim3 grid((unsigned)((row_bytes + 16 * 256 - 1) / (16 * 256)), (unsigned)rows);
     k_scatter_rows<<<grid, 256, 0, (hipStream_t)stream>>>((const uint8_t *)d_part, (uint8_t *)d_full, (int)rows, row_bytes,
                                                           row_block, n_parts, part);
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+extern "C" int lt_scatter_rows_indexed_dev(const void *d_rows, void *d_full, const int64_t *d_row_index, int64_t n_rows,
+                                           int64_t height, int64_t row_bytes, void *stream)
+{
+    int rc = require_device();
+    if (rc) return rc;
+    if (n_rows < 0 || height <= 0 || row_bytes <= 0 || n_rows > 65535 * (int64_t)65535)
+        return fail(LT_ERR_INVALID_ARG, "bad scatter arguments (n_rows %lld, height %lld, row_bytes %lld)", (long long)n_rows,
+                    (long long)height, (long long)row_bytes);
+    if (n_rows == 0) return LT_OK;
+    if (!d_rows || !d_full || !d_row_index) return fail(LT_ERR_INVALID_ARG, "null pointer");
+    // grid.y carries the row (at most 65535 per launch): a frame of more rows goes in slices
+    for (int64_t r0 = 0; r0 < n_rows; r0 += 65535) {
+        int64_t nr = n_rows - r0 < 65535 ? n_rows - r0 : 65535;
+        dim3 grid((unsigned)((row_bytes + 16 * 256 - 1) / (16 * 256)), (unsigned)nr);
+        k_scatter_rows_indexed<<<grid, 256, 0, (hipStream_t)stream>>>((const uint8_t *)d_rows + r0 * row_bytes, (uint8_t *)d_full,
+                                                                      d_row_index + r0, nr, height, row_bytes);
+    }
     HIP_TRY(hipGetLastError());
     return LT_OK;
 }

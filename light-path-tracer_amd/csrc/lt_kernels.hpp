@@ -1010,6 +1010,26 @@ __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__rest
         for (int64_t j = i; j < i + 16 && j < row_bytes; ++j) dst[j] = src[j];
     }
 }
+
+// The same with the destination row of every source row read from a list: row_index[i] is where source row i goes.
+// One launch un-permutes a whole frame received partition after partition (any row-block -> rank table); an entry
+// outside [0, height) is skipped, so a bad list cannot fault.
+__global__ void k_scatter_rows_indexed(const uint8_t *__restrict__ src_rows, uint8_t *__restrict__ full,
+                                       const int64_t *__restrict__ row_index, int64_t n_rows, int64_t height, int64_t row_bytes)
+{
+    int64_t i = blockIdx.y;
+    if (i >= n_rows) return;
+    int64_t grow = row_index[i];
+    if (grow < 0 || grow >= height) return;
+    const uint8_t *src = src_rows + i * row_bytes;
+    uint8_t *dst = full + grow * row_bytes;
+    int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (b + 16 <= row_bytes && (row_bytes & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst + b) = *reinterpret_cast<const uint4 *>(src + b);
+    } else {
+        for (int64_t j = b; j < b + 16 && j < row_bytes; ++j) dst[j] = src[j];
+    }
+}
 #endif // LT_KERNEL_TEMPLATES_ONLY
 
 #if defined(LT_PROBES) && !defined(LT_KERNEL_TEMPLATES_ONLY)

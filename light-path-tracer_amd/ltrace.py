@@ -103,6 +103,7 @@ SIGNATURES = {
                             C.POINTER(Stats)]),
     "lt_scatter_rows_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_void_p]),
+    "lt_scatter_rows_indexed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "lt_timing_collect": (C.c_int, [_dp, _dp, _dp, C.POINTER(C.c_int32)]),
     "lt_pixel_angles": (C.c_int, [C.POINTER(Camera), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lt_shade": (C.c_int, [C.POINTER(Camera), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -257,41 +258,51 @@ def global_rows(height, row_block, n_parts, part):
 # numpy array costs an extra pass through the library's staging area.  render() therefore hands out arrays
 # backed by lt_host_alloc blocks.  Blocks are recycled by size once the last numpy view of them is gone
 # (allocating pinned memory costs milliseconds, a 4096^2 frame every call).
+import threading
 import weakref
 
 _pinned_free = {}     # nbytes -> [address, ...]
 _PINNED_POOL_LIMIT = int(os.environ.get("LTRACE_PINNED_POOL_MB", "2048")) << 20
+_PINNED_OUTPUTS = os.environ.get("LTRACE_PINNED_OUTPUTS", "1") != "0"    # 0: render() returns ordinary numpy arrays
 _pinned_pooled = 0
+_pinned_lock = threading.Lock()      # finalizers run on whatever thread drops the last reference
 
 
 def _pinned_release(addr, nbytes):
     global _pinned_pooled
     if _lib is None:
         return
-    if _pinned_pooled + nbytes <= _PINNED_POOL_LIMIT:
-        _pinned_free.setdefault(nbytes, []).append(addr)
-        _pinned_pooled += nbytes
-    else:
-        _lib.lt_host_free(C.c_void_p(addr))
+    with _pinned_lock:
+        if _pinned_pooled + nbytes <= _PINNED_POOL_LIMIT:
+            _pinned_free.setdefault(nbytes, []).append(addr)
+            _pinned_pooled += nbytes
+            return
+    _lib.lt_host_free(C.c_void_p(addr))
 
 
-def pinned_empty(shape, dtype):
+def pinned_empty(shape, dtype, strict=False):
     """numpy array of `shape` / `dtype` in pinned host memory (lt_host_alloc); freed or recycled when the array
-    and all its views are gone.  Falls back to ordinary memory for empty arrays."""
+    and all its views are gone.  Ordinary memory for empty arrays, with LTRACE_PINNED_OUTPUTS=0, and -- unless
+    `strict` -- when the pinned allocation fails (a caller that keeps many frames alive holds that much
+    non-swappable memory; lt_render accepts a pageable destination, it is only slower the first time it sees it)."""
     global _pinned_pooled
     dtype = np.dtype(dtype)
     nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-    if nbytes == 0:
+    if nbytes == 0 or (not _PINNED_OUTPUTS and not strict):
         return np.empty(shape, dtype=dtype)
     nbytes = (nbytes + 4095) & ~4095
-    lst = _pinned_free.get(nbytes)
-    if lst:
-        addr = lst.pop()
-        _pinned_pooled -= nbytes
-    else:
+    addr = None
+    with _pinned_lock:
+        lst = _pinned_free.get(nbytes)
+        if lst:
+            addr = lst.pop()
+            _pinned_pooled -= nbytes
+    if addr is None:
         addr = load().lt_host_alloc(nbytes)
         if not addr:
-            raise LtraceError(ERR_HIP, load().lt_last_error().decode("utf-8", "replace"))
+            if strict:
+                raise LtraceError(ERR_HIP, load().lt_last_error().decode("utf-8", "replace"))
+            return np.empty(shape, dtype=dtype)
     buf = (C.c_ubyte * nbytes).from_address(addr)
     weakref.finalize(buf, _pinned_release, addr, nbytes).atexit = False   # at exit the process frees it
     n = int(np.prod(shape, dtype=np.int64))
@@ -463,6 +474,12 @@ def scatter_rows_dev(d_part, d_full, height, width, elem_bytes, row_block, n_par
                                       n_parts, part, C.c_void_p(stream) if stream else None))
 
 
+def scatter_rows_indexed_dev(d_rows, d_full, d_row_index, n_rows, height, row_bytes, stream=0):
+    """Source row i (device, row_bytes each) -> row d_row_index[i] (device int64) of the full frame; one launch."""
+    _check(load().lt_scatter_rows_indexed_dev(C.c_void_p(d_rows), C.c_void_p(d_full), C.c_void_p(d_row_index), n_rows, height,
+                                              row_bytes, C.c_void_p(stream) if stream else None))
+
+
 def timing_collect():
     a, b, c = C.c_double(), C.c_double(), C.c_double()
     n = C.c_int32()
@@ -478,8 +495,9 @@ def release_stream(stream_ptr):
 def shutdown():
     if _lib is not None:
         _lib.lt_shutdown()
-        for nbytes, lst in _pinned_free.items():
-            for addr in lst:
-                _lib.lt_host_free(C.c_void_p(addr))
-        _pinned_free.clear()
-        globals()['_pinned_pooled'] = 0
+        with _pinned_lock:
+            blocks = [addr for lst in _pinned_free.values() for addr in lst]
+            _pinned_free.clear()
+            globals()['_pinned_pooled'] = 0
+        for addr in blocks:
+            _lib.lt_host_free(C.c_void_p(addr))

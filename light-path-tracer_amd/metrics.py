@@ -13,9 +13,9 @@ Host-side scalar physics that is not on the per-pixel path (critical angles,
 impact parameters, the 8-D Hamiltonian right-hand side consumed by
 scipy.solve_ivp in geodesic_tracer.py) is plain numpy.
 
-Extra, backend-only knobs (keyword arguments with reference-compatible defaults
-absent): integrator = 'rk4' | 'dp45' | 'dp45_exact', precision = 32 | 64, schedule =
-'direct' | 'queue'.
+Extra, backend-only knobs (keyword arguments; left out, the reference's own
+arithmetic is used -- float64, DP45 for Kerr): integrator = 'rk4' | 'dp45' |
+'dp45_exact', precision = 32 | 64, schedule = 'direct' | 'queue'.
 """
 from abc import ABC, abstractmethod
 
@@ -23,13 +23,15 @@ import numpy as np
 
 import ltrace
 
-# Backend defaults.  DP45 (float64) is the reference's production Kerr integrator (metrics.py:419-567) and therefore
-# the drop-in default -- with the step controller evaluated in float64 as the reference writes it ('dp45_exact': every
-# accept / reject decision of the reference's own run is reproduced; since round 2 it costs 4 % over 'dp45', whose
-# controller is float32); 'rk4' + precision 32 is the north-star kernel (reference metrics.py:570-658, float32),
-# about 1.7x faster per ray -- what bench.py measures.
+# Backend defaults = the reference's own arithmetic, so that switching to this package changes where rays are integrated
+# and nothing else: float64 everywhere (the reference has no float32 path), and for Kerr its production integrator, DP45
+# (metrics.py:419-567), with the step controller evaluated in float64 as the reference writes it ('dp45_exact': the
+# accept / reject sequence of the reference's own run, see INTEGRATION.md for what "exact" covers; 4 % over 'dp45',
+# whose controller is float32).  The fast path is opt-in: integrator='rk4', precision=32 is the north-star kernel
+# (reference metrics.py:570-658 in float32), about 1.7x faster per ray -- what bench.py's headline measures --
+# and Schwarzschild(precision=32) the float32 orbit-equation tracer.
 DEFAULT_KERR_INTEGRATOR = "dp45_exact"
-DEFAULT_PRECISION = 32
+DEFAULT_PRECISION = 64
 DEFAULT_SCHEDULE = "direct"
 
 _OUTCOME = {1: "escaped", -1: "captured", 0: "invalid"}

@@ -1,7 +1,7 @@
 """Row sharding of a frame across the GPUs of one node, one process per GPU.
 
 The frame tiles trivially: pixels are independent, so ranks share no data while rendering and the
-only exchange is the gather of the finished framebuffer to rank 0 (RCCL over xGMI when the process
+only exchange is the finished framebuffer going to rank 0 (RCCL send/recv over xGMI when the process
 group's backend is "nccl"; the same code runs on "gloo" for the CPU tests).
 
 Partition: block-cyclic rows -- block b of `row_block` rows belongs to rank b % world.  Row cost is
@@ -58,13 +58,22 @@ def balance_blocks(block_cost, block_chain, world, chain_cost=1.0, share=0.65):
 
 
 class FrameGather:
-    """Gathers per-rank row partitions (R_rank, W, C) of one dtype to the full (H, W, C) frame on rank 0.
+    """Brings per-rank row partitions (R_rank, W, C) of one dtype together as the full (H, W, C) frame on rank 0.
 
-    Buffers are allocated once; `gather(local)` is collective.  Partitions are padded to the largest
-    partition so a plain dist.gather (ncclGather-style send/recv into rank 0) suffices.
-    `owner`: optional row-block -> rank table (balance_blocks); default block-cyclic."""
+    Every rank sends exactly the rows it owns -- one grouped point-to-point exchange (`dist.batch_isend_irecv`: on the
+    "nccl" backend a single ncclGroupStart/End of ncclSend / ncclRecv over xGMI, the seven peers of an 8-GPU node on
+    seven links into rank 0 at once) -- into a rank-major staging frame on rank 0: rank r's rows at
+    [offset_r, offset_r + rows_r).  Rank 0 renders straight into its own piece of it.  One scatter launch
+    (lt_scatter_rows_indexed_dev: staging row i -> frame row index[i]) then un-permutes the whole frame, whatever the
+    assignment of row blocks to ranks.  Nothing is padded: with a cost-weighted table the partitions differ by up to
+    3.6x (224 ... 816 rows of 4096) and a padded `dist.gather` would move 1.6x the frame.
+    Buffers are allocated once; `gather()` is collective.
+    `owner`: optional row-block -> rank table (balance_blocks); default block-cyclic.
+    LT_FRAME_GATHER=padded in the environment selects the old exchange (dist.gather of partitions padded to the
+    largest) -- a diagnostic switch for a transport that mishandles grouped send/recv, not a second product path."""
 
     def __init__(self, height, width, channels, dtype, device, row_block, world=None, rank=None, owner=None):
+        import os
         self.world = dist.get_world_size() if world is None else world
         self.rank = dist.get_rank() if rank is None else rank
         self.h, self.w, self.c = height, width, channels
@@ -72,55 +81,82 @@ class FrameGather:
         self.device = torch.device(device)
         self.owner = None if owner is None else np.ascontiguousarray(owner, dtype=np.uint16)
         if self.owner is not None:
-            self._rows_of = [torch.from_numpy(ltrace.owned_rows(height, row_block, self.owner, r)) for r in range(self.world)]
-            self.rows = [int(x.numel()) for x in self._rows_of]
+            rows_of = [ltrace.owned_rows(height, row_block, self.owner, r) for r in range(self.world)]
         else:
-            self._rows_of = None
-            self.rows = [local_rows(height, row_block, self.world, r) for r in range(self.world)]
+            rows_of = [ltrace.global_rows(height, row_block, self.world, r) for r in range(self.world)]
+        self.rows = [int(x.size) for x in rows_of]
+        if sum(self.rows) != height or not np.array_equal(np.sort(np.concatenate(rows_of)), np.arange(height)):
+            raise ValueError("the row partition does not cover every row of the frame exactly once")
+        self.offsets = [int(x) for x in np.concatenate([[0], np.cumsum(self.rows)])]
         self.rows_max = max(self.rows)
-        self.local = torch.empty((self.rows_max, width, channels), dtype=dtype, device=self.device)
-        self.full = None
-        self.parts = None
-        if self.rank == 0:
-            self.full = torch.empty((height, width, channels), dtype=dtype, device=self.device)
-            if self.world > 1:
+        self.padded = os.environ.get("LT_FRAME_GATHER", "") == "padded" and self.world > 1
+        self.full = self.staging = self.index = self.parts = None
+        if self.world == 1:
+            self.local = torch.empty((self.rows[0], width, channels), dtype=dtype, device=self.device)
+        elif self.padded:
+            self.local = torch.empty((self.rows_max, width, channels), dtype=dtype, device=self.device)
+            if self.rank == 0:
                 self.parts = [torch.empty_like(self.local) for _ in range(self.world)]
-        self._index = None
-        if self._rows_of is not None and self.rank == 0:
-            self._index = [x.to(self.device) for x in self._rows_of]
+        elif self.rank == 0:
+            self.staging = torch.empty((height, width, channels), dtype=dtype, device=self.device)
+            self.local = self.staging[: self.rows[0]]
+        else:
+            self.local = torch.empty((self.rows[self.rank], width, channels), dtype=dtype, device=self.device)
+        if self.rank == 0 and self.world > 1:
+            self.full = torch.empty((height, width, channels), dtype=dtype, device=self.device)
+            self.index = torch.from_numpy(np.concatenate(rows_of).astype(np.int64)).to(self.device)
+            self._index_of = [torch.from_numpy(x.astype(np.int64)).to(self.device) for x in rows_of] if self.padded else None
 
     def local_view(self):
         """(R_rank, W, C) view this rank renders into."""
         return self.local[: self.rows[self.rank]]
 
+    def _exchange(self):
+        staged = self.device.type == "cuda" and dist.get_backend() == "gloo"   # rehearsals only: gloo moves host tensors
+        if self.padded:
+            if staged:
+                host = [torch.empty_like(self.local, device="cpu") for _ in range(self.world)] if self.rank == 0 else None
+                dist.gather(self.local.cpu(), host, dst=0)
+                if self.rank == 0:
+                    for p_, h_ in zip(self.parts, host):
+                        p_.copy_(h_)
+            else:
+                dist.gather(self.local, self.parts, dst=0)
+            return
+        if self.rank == 0:
+            pieces = [(r, self.staging[self.offsets[r]: self.offsets[r + 1]]) for r in range(1, self.world) if self.rows[r]]
+            bufs = [(r, torch.empty(v.shape, dtype=v.dtype, device="cpu") if staged else v) for r, v in pieces]
+            ops = [dist.P2POp(dist.irecv, b, r) for r, b in bufs]
+            if ops:
+                for wk in dist.batch_isend_irecv(ops):
+                    wk.wait()
+            if staged:
+                for (_, v), (_, b) in zip(pieces, bufs):
+                    v.copy_(b)
+        elif self.rows[self.rank]:
+            src = self.local_view()
+            for wk in dist.batch_isend_irecv([dist.P2POp(dist.isend, src.cpu() if staged else src, 0)]):
+                wk.wait()
+
     def gather(self, stream_ptr=0):
-        """Collective.  Rank 0 returns the assembled (H, W, C) frame, other ranks None."""
+        """Collective.  Rank 0 returns the assembled (H, W, C) frame, other ranks None.
+        With a CUDA device the caller's current torch stream must be the stream behind `stream_ptr` (bench.py wraps the
+        call in torch.cuda.stream): the exchange is ordered by torch on the current stream, the scatter by the pointer."""
         if self.world == 1:
-            # one partition = the whole frame, already in row order
-            return self.local[: self.h]
-        if self.device.type == "cuda" and dist.get_backend() == "gloo":
-            # rehearsals only (bench.py --backend gloo on a box with fewer GPUs than ranks): gloo gathers host tensors
-            host = [torch.empty_like(self.local, device="cpu") for _ in range(self.world)] if self.rank == 0 else None
-            dist.gather(self.local.cpu(), host, dst=0)
-            if self.rank == 0:
-                for p_, h_ in zip(self.parts, host):
-                    p_.copy_(h_)
-        else:
-            dist.gather(self.local, self.parts, dst=0)
+            return self.local[: self.h]          # one partition = the whole frame, already in row order
+        self._exchange()
         if self.rank != 0:
             return None
-        elem = self.local.element_size() * self.c
-        for r in range(self.world):
-            if self.rows[r] == 0:
-                continue
-            if self.device.type == "cuda" and self.owner is None:
-                ltrace.scatter_rows_dev(self.parts[r].data_ptr(), self.full.data_ptr(), self.h, self.w, elem,
-                                        self.row_block, self.world, r, stream_ptr)
-            else:
-                if self._index is None:
-                    self._index = [global_row_index(self.h, self.row_block, self.world, q).to(self.device)
-                                   for q in range(self.world)]
-                self.full.index_copy_(0, self._index[r], self.parts[r][: self.rows[r]])   # table mode, or CPU
+        row_bytes = self.w * self.c * self.full.element_size()
+        if self.padded:                          # diagnostic exchange: per-partition un-permute on the current stream
+            for r in range(self.world):
+                if self.rows[r]:
+                    self.full.index_copy_(0, self._index_of[r], self.parts[r][: self.rows[r]])
+        elif self.device.type == "cuda":
+            ltrace.scatter_rows_indexed_dev(self.staging.data_ptr(), self.full.data_ptr(), self.index.data_ptr(), self.h, self.h,
+                                            row_bytes, stream_ptr)
+        else:
+            self.full.index_copy_(0, self.index, self.staging)
         return self.full
 
 

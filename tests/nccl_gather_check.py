@@ -33,22 +33,30 @@ def main():
     cam = ltrace.Camera(W, H, 2 * np.arctan(np.tan(fov_v / 2) * W / H), fov_v, 0.02, -0.03, 50.0, np.pi / 2)
     met = ltrace.Metric(1, 0, 1.0, 0.9)
     stream = torch.cuda.current_stream(dev)
-    fg = sharding.FrameGather(H, W, 4, torch.uint8, dev, rb, world, rank)
-    o = ltrace.default_opts(precision=32, n_parts=world, part=rank, row_block=rb)
-    o.stream = stream.cuda_stream
-    for _ in range(2):                            # buffers are reused frame after frame
-        ltrace.render_dev(cam, met, o, d_rgba=fg.local.data_ptr())
-        full = fg.gather(stream.cuda_stream)
-    torch.cuda.synchronize(dev)
-    ok = True
+    whole = None
     if rank == 0:
         whole = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
         o1 = ltrace.default_opts(precision=32)
         o1.stream = stream.cuda_stream
         ltrace.render_dev(cam, met, o1, d_rgba=whole.data_ptr())
         torch.cuda.synchronize(dev)
-        ok = bool(torch.equal(full, whole))
-        print(f"{dist.get_backend()} gather over {world} ranks: frame {'identical' if ok else 'DIFFERS'}", flush=True)
+    ok = True
+    # block-cyclic, then a row-block -> rank table with partitions of very different sizes (what --balance cost produces)
+    nb = (H + rb - 1) // rb
+    table = (np.random.default_rng(5).integers(0, world, nb) * (np.arange(nb) % 3 != 0)).astype(np.uint16)
+    for owner in (None, table):
+        fg = sharding.FrameGather(H, W, 4, torch.uint8, dev, rb, world, rank, owner=owner)
+        o = ltrace.default_opts(precision=32, n_parts=world, part=rank, row_block=rb, block_owner=owner)
+        o.stream = stream.cuda_stream
+        for _ in range(2):                            # buffers are reused frame after frame
+            ltrace.render_dev(cam, met, o, d_rgba=fg.local_view().data_ptr())
+            full = fg.gather(stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            same = bool(torch.equal(full, whole))
+            ok = ok and same
+            print(f"{dist.get_backend()} exchange over {world} ranks, {'block-cyclic' if owner is None else 'table ' + str(fg.rows)}: "
+                  f"frame {'identical' if same else 'DIFFERS'}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     return 0 if ok else 1

@@ -37,7 +37,7 @@ def test_batch_binding_stub_of_section_b():
     big_fa, big_w = np.full(2 * n, np.nan), np.zeros(2 * n, dtype=np.int64)
     ns["_trace_rays_batch_kerr"](1.0, 0.9, 1.4358898943540672, 50.0, al, th, np.pi / 2, 5000.0, rf, big_fa[n:], big_w[n:])
     fa3, w3 = np.full(n, np.nan), np.zeros(n, dtype=np.int64)
-    metrics.Kerr(1.0, 0.9, integrator="rk4", precision=32).trace_rays_batch(50.0, al, th, np.pi / 2, rf, fa3, w3)
+    metrics.Kerr(1.0, 0.9).trace_rays_batch(50.0, al, th, np.pi / 2, rf, fa3, w3)   # the plugin default == the stub's `2, 64`
     assert np.all(np.isnan(big_fa[:n])) and np.all(big_w[:n] == 0)
     assert np.array_equal(big_w[n:], w3) and np.array_equal(big_fa[n:], fa3, equal_nan=True)
     assert 0.5 < np.isfinite(fa3).mean() < 0.95

@@ -112,6 +112,30 @@ def test_fused_path_equals_staged_path(a):
     np.testing.assert_array_equal(fused["rgb"], staged)
 
 
+def test_drop_in_defaults_are_the_reference_arithmetic(tmp_path):
+    """Switching to this package without naming a backend knob must give the reference's numbers: the plugin classes
+    default to float64 (the reference has no float32 path, metrics.py:831-833) and, for Kerr, to its production
+    integrator.  `image_lens.main(a=0)` with nothing but an image is checked against the reference's own lookup and
+    picture of the same frame (F4 / F5) at the float64 tolerance."""
+    import matplotlib.image as mpimg
+    g, m = _g("48x64_a0")
+    assert metrics.Schwarzschild().precision == 64 and metrics.Kerr(1.0, 0.9).precision == 64
+    assert metrics.Kerr(1.0, 0.9).integrator == "dp45_exact"
+    png = tmp_path / "bg.png"
+    mpimg.imsave(str(png), g["background"])                       # 8-bit exact: the fixture's texture is uint8 / 255
+    img = image_lens.main(a=0.0, r_obs_mult=m["r_obs"], image_path=str(png), output_path=str(tmp_path / "out.png"))
+    fov = (m["hfov"], m["vfov"])
+    out = image_lens.render_frame(g["background"], metrics.Schwarzschild(), m["r_obs"], fov, want=("fa", "winding", "rgb"))
+    np.testing.assert_array_equal(img, out["rgb"])                # main() renders with the metric's defaults
+    assert np.array_equal(np.isnan(out["fa"]), np.isnan(g["final_alpha"]))
+    assert np.nanmax(np.abs(out["fa"] - g["final_alpha"])) <= 1e-6   # float64 kernel vs the reference's float64 tracer
+    np.testing.assert_array_equal(out["winding"], g["winding"])
+    assert (np.abs(img - g["lensed"]).max(axis=-1) > 0).mean() <= 0.005   # nearest-neighbour: a 1e-7 rad change can move a texel
+    # the explicit fast path still exists and is float32
+    fast = image_lens.render_frame(g["background"], metrics.Schwarzschild(precision=32), m["r_obs"], fov, want=("fa",))
+    assert 1e-9 < np.nanmax(np.abs(fast["fa"] - g["final_alpha"])) <= 2e-4
+
+
 def test_cli_main_runs_end_to_end(tmp_path, capsys):
     out = tmp_path / "lensed.png"
     img = image_lens.main(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), output_path=str(out))

@@ -81,6 +81,30 @@ def test_two_rank_gather_with_a_block_owner_table(tmp_path):
     assert os.path.exists(out)
 
 
+def test_three_rank_gather_unpadded_with_unequal_and_empty_partitions(tmp_path):
+    """Exact-size exchange: partitions of 48, 22 and 0 rows (a rank may own nothing) -- nothing is padded to the largest."""
+    height, width, rb = 70, 12, 8
+    owner = np.array([0, 0, 1, 0, 0, 1, 0, 0, 1], dtype=np.uint16)       # rank 2 owns no block; the last block is short
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(3, _free_port(), height, width, rb, out, owner), nprocs=3, join=True)
+    assert os.path.exists(out)
+    fg = sharding.FrameGather(height, width, 4, torch.uint8, "cpu", rb, 3, 1, owner=owner)
+    assert fg.rows == [48, 22, 0] and tuple(fg.local.shape) == (22, width, 4)   # a peer allocates its own rows only
+
+
+def test_padded_diagnostic_exchange_gives_the_same_frame(tmp_path, monkeypatch):
+    monkeypatch.setenv("LT_FRAME_GATHER", "padded")
+    owner = np.array([1, 1, 0, 1, 0, 0, 0, 1, 1], dtype=np.uint16)
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(2, _free_port(), 70, 12, 8, out, owner), nprocs=2, join=True)
+    assert os.path.exists(out)
+
+
+def test_a_table_that_is_not_a_partition_is_refused():
+    with pytest.raises(ValueError):
+        sharding.FrameGather(64, 8, 4, torch.uint8, "cpu", 16, 2, 0, owner=np.array([0, 0, 0], dtype=np.uint16))   # 4 blocks, 3 entries
+
+
 def test_balance_blocks_properties():
     rng = np.random.default_rng(0)
     nb = 256

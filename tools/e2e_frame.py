@@ -12,7 +12,7 @@ cam = ltrace.Camera(size, size, fov, fov, 0.0, 0.0, 50.0, np.pi / 2)
 met = ltrace.Metric(1, 0, 1.0, 0.9)
 o = ltrace.default_opts(precision=32)
 for name in ("pinned", "pageable"):
-    rgba = ltrace.pinned_empty((size, size, 4), np.uint8) if name == "pinned" else np.zeros((size, size, 4), np.uint8)
+    rgba = ltrace.pinned_empty((size, size, 4), np.uint8, strict=True) if name == "pinned" else np.zeros((size, size, 4), np.uint8)
     st = ltrace.Stats()
     call = lambda: ltrace._check(ltrace.load().lt_render(C.byref(cam), C.byref(met), C.byref(o), None, 3, None, None, None, None, None,
                                                          C.c_void_p(rgba.ctypes.data), C.byref(st)))
