@@ -44,7 +44,28 @@ def test_north_star_line_has_the_contract_fields_and_an_honest_roofline():
     assert d["chain_floor"]["longest_ray_steps"] > 2000 and d["chain_floor"]["alone_ms"] < r["avg_launch_ms"]
     assert 5.0 < d["end_to_end_ms"]["pinned_dst_ms"] < 40.0
     assert d["cpu_baseline"]["unit"] == "Mrays/s" and d["cpu_baseline"]["cores"] >= 1 and "perf build" in d["cpu_baseline"]["kind"]
-    assert d["ranks"]["rccl_world"] == 1
+    assert d["ranks"]["rccl_world"] == 1 and d["ranks"]["devices"][0]["rank"] == 0
+    assert d["config"]["balance"] == {"requested": "auto", "used": "cyclic"}
+    # the reference's production path (DP45 float64, the plugin default) is measured in the same line, with its own
+    # roofline from a committed PMC count and its own CPU baseline
+    p = d["production_path"]
+    assert p["dtype"] == "f64" and p["steps"] == 3 and p["config"]["workload"] == "kerr_a0.9_shadow_4096x4096_r50_dp45_exact"
+    assert p["config"]["rays_per_frame"] == 4096 * 4096 and 40 < p["config"]["mean_dp45_attempts_per_ray"] < 80
+    assert abs(p["value"] - 4096 * 4096 / p["ms_per_step"] / 1e3) < 0.01 * p["value"]
+    pr = p["roofline"]
+    assert pr["bound"] == "valu_issue_fp64" and pr["peak"] == 78.6 and "Dp45" not in pr["kernel"] and "dp45_exact" in pr["kernel"]
+    assert pr["frac"] is not None, "profiles/valu_counts.json has no record for the production-path workload"
+    assert 0.5 < pr["frac"] <= pr["frac_at_held_clock"] <= 1.0
+    assert pr["avg_launch_ms"] + pr["other_kernels_ms"]["prologue"] + pr["other_kernels_ms"]["epilogue"] <= p["ms_per_step"] * 1.02
+    assert p["cpu_baseline"]["unit"] == "Mrays/s" and "dp45" in p["cpu_baseline"]["sample"]
+    assert p["cpu_baseline"]["mean_rhs_evals_per_ray"] < d["cpu_baseline"]["mean_rhs_evals_per_ray"]     # adaptive: fewer evaluations
+    # what each rank of a 2 / 4 / 8 GPU run renders, one at a time on this GPU (a projection, labelled as one)
+    for integ in ("rk4", "dp45_exact"):
+        pj = d["projected_ranks"][integ]
+        assert "PROJECTION" in pj["what"]
+        for n in (2, 4, 8):
+            assert len(pj[str(n)]["frame_ms_per_rank"]) == n and pj[str(n)]["slowest_rank_ms"] == max(pj[str(n)]["frame_ms_per_rank"])
+        assert pj["8"]["slowest_rank_ms"] < pj["2"]["slowest_rank_ms"] < d["ms_per_step"] * (1.0 if integ == "rk4" else 2.0)
 
 
 def test_other_workloads_and_flags():

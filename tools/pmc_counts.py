@@ -9,7 +9,8 @@ Each figure is keyed by bench.py's `config.profile_key` and stamped with the lib
 a figure whose build id is not the loaded library's.  One rocprofv3 run per counter group (SQ, FETCH_SIZE,
 WRITE_SIZE: separate passes, no trace domains besides --kernel-trace).
 
-usage (through gpurun):  python3 tools/pmc_counts.py [--quick]     -> gpurun_out/pmc_counts/{valu_counts,hbm_traffic}.json + summary.txt
+usage (through gpurun):  python3 tools/pmc_counts.py [--quick | --only=tag,tag]   (--quick: the two workloads of the driver's bench line)
+                         -> gpurun_out/pmc_counts/{valu_counts,hbm_traffic}.json + summary.txt
 then here:               cp gpurun_out/pmc_counts/*.json profiles/  (tools/refresh_profiles.sh collect does it)
 """
 import csv
@@ -29,6 +30,7 @@ WORKLOADS = [
     ("north_star_queue", ["--schedule", "queue"]),
     ("kerr_2048", ["--size", "2048"]),
     ("image_lens_r100_bg", ["--r-obs", "100", "--background"]),
+    ("dp45_exact_f64", ["--integrator", "dp45_exact", "--precision", "64"]),   # the production-path region of the bench line
     ("dp45_f64", ["--integrator", "dp45", "--precision", "64"]),
     ("kerr_8192_a099", ["--size", "8192", "--a", "0.99", "--steps", "2"]),
 ]
@@ -66,14 +68,28 @@ def main():
     valu = {"workloads": {}}
     hbm = {"workloads": {}}
     text = []
-    for tag, args in (WORKLOADS[:1] if quick else WORKLOADS):
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--only=")]
+    todo = [w for w in WORKLOADS if w[0] in only[0]] if only else (
+        [w for w in WORKLOADS if w[0] in ("north_star", "dp45_exact_f64")] if quick else WORKLOADS)
+    # a partial run (--quick / --only=...) refreshes its workloads and keeps the other records (each carries its own
+    # build id; bench.py marks a record measured on another build as stale and prints no traffic from it)
+    for name, obj in (("valu_counts.json", valu), ("hbm_traffic.json", hbm)):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                old = json.load(f)
+            for k, rec in (old.get("workloads") or {}).items():
+                rec.setdefault("build_id", old.get("build_id"))
+                obj["workloads"][k] = rec
+        except (OSError, ValueError):
+            pass
+    for tag, args in todo:
         j, c = profiled(tag + "_sq", SQ, args)
         if not j:
             continue
         key, bid = j["config"]["profile_key"], j["config"]["build_id"]
         valu["build_id"] = hbm["build_id"] = bid
         iters = j["roofline"]["executed"]["wave_iters_per_launch"]
-        rec = {"valu_insts": int(c.get(("integrate", "SQ_INSTS_VALU"), 0)), "wave_iters": int(iters),
+        rec = {"build_id": bid, "valu_insts": int(c.get(("integrate", "SQ_INSTS_VALU"), 0)), "wave_iters": int(iters),
                "salu_insts": int(c.get(("integrate", "SQ_INSTS_SALU"), 0)),
                "lane_utilisation": round(c.get(("integrate", "SQ_THREAD_CYCLES_VALU"), 0) / max(c.get(("integrate", "SQ_ACTIVE_INST_VALU"), 1), 1) / 64, 4),
                "grbm_gui_active": int(c.get(("integrate", "GRBM_GUI_ACTIVE"), 0)),
@@ -89,7 +105,7 @@ def main():
         if jf and jw and ("integrate", "FETCH_SIZE") in cf and ("integrate", "WRITE_SIZE") in cw:
             fetch_kb, write_kb = cf[("integrate", "FETCH_SIZE")], cw[("integrate", "WRITE_SIZE")]
             total = int(fetch_kb * 1024 * 2 + write_kb * 1024)
-            hbm["workloads"][key] = {"bytes_per_launch": total, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
+            hbm["workloads"][key] = {"build_id": bid, "bytes_per_launch": total, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
                                      "algorithmic_bytes_per_launch": j["roofline"]["algorithmic_bytes_per_launch"],
                                      "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), FETCH_SIZE x 2 "
                                                "(gfx950: it counts half of a wide coalesced read) + WRITE_SIZE, unit KB; tools/pmc_counts.py"}
