@@ -107,7 +107,7 @@ def _install_counters():
 
 
 def _trace_one(job):
-    kind, M, a, r_obs, alpha, theta, refine = job
+    kind, M, a, r_obs, alpha, theta, refine, theta_obs = job
     _install_counters()
     _COUNTER[0] = 0
     if kind == "schw":
@@ -118,11 +118,11 @@ def _trace_one(job):
         lam = max(5000.0, 6.0 * r_obs)
         fn = (ref_metrics._kerr_trace_ray_numba if kind == "dp45"
               else ref_metrics._kerr_trace_ray_rk4_numba)
-        s, fa, nh = fn(M, a, r_plus, r_obs, alpha, theta, np.pi / 2, lam, 1.0, bool(refine))
+        s, fa, nh = fn(M, a, r_plus, r_obs, alpha, theta, theta_obs, lam, 1.0, bool(refine))
     return int(s), float(fa), int(nh), int(_COUNTER[0])
 
 
-def trace_grid(pool, kind, M, a, r_obs, n, refine_mode, fov_deg=40.0):
+def trace_grid(pool, kind, M, a, r_obs, n, refine_mode, fov_deg=40.0, theta_obs=np.pi / 2):
     fov = np.radians(fov_deg)
     alpha32, theta, cols = pixel_grid(n, n, fov, fov)
     alpha = alpha32.astype(np.float64).ravel()
@@ -131,7 +131,7 @@ def trace_grid(pool, kind, M, a, r_obs, n, refine_mode, fov_deg=40.0):
         refine = np.broadcast_to(cols[None, :], (n, n)).ravel()
     else:
         refine = np.zeros(n * n, dtype=bool)
-    jobs = [(kind, M, a, r_obs, float(alpha[i]), float(th[i]), bool(refine[i]))
+    jobs = [(kind, M, a, r_obs, float(alpha[i]), float(th[i]), bool(refine[i]), float(theta_obs))
             for i in range(n * n)]
     t0 = time.time()
     out = pool.map(_trace_one, jobs, chunksize=64)
@@ -142,7 +142,7 @@ def trace_grid(pool, kind, M, a, r_obs, n, refine_mode, fov_deg=40.0):
     ev = np.array([o[3] for o in out], dtype=np.int32)
     print(f"  {kind} a={a} r_obs={r_obs} n={n} refine={refine_mode}: {dt:.1f}s "
           f"({n*n/dt:.0f} rays/s), mean evals {ev.mean():.1f}, max {ev.max()}")
-    return dict(kind=kind, M=M, a=a, r_obs=r_obs, n=n, fov_deg=fov_deg,
+    return dict(kind=kind, M=M, a=a, r_obs=r_obs, n=n, fov_deg=fov_deg, theta_obs=float(theta_obs),
                 refine_mode=refine_mode, alpha=alpha, theta=th,
                 refine=refine.astype(np.uint8), status=status, final_alpha=fa,
                 n_half=nh, rhs_evals=ev)
@@ -198,12 +198,19 @@ def f2_ic():
     save("kerr_ic.npz", inputs=np.array(ins), outputs=np.array(outs))
 
 
-def f3_rays(sizes):
+def f3_rays(sizes, skip_existing=False):
     with Pool(8) as pool:
-        for (kind, a, r_obs, n, mode) in sizes:
-            g = trace_grid(pool, kind, 1.0, a, r_obs, n, mode)
-            name = f"rays_{kind}_a{str(a).replace('.', 'p')}_r{int(r_obs)}_n{n}_{mode}.npz"
-            meta = {k: g[k] for k in ("kind", "M", "a", "r_obs", "n", "fov_deg", "refine_mode")}
+        for case in sizes:
+            kind, a, r_obs, n, mode = case[:5]
+            theta_obs = case[5] if len(case) > 5 else np.pi / 2      # observer inclination (metrics.py:148-218 takes any)
+            name = f"rays_{kind}_a{str(a).replace('.', 'p').replace('-', 'm')}_r{int(r_obs)}_n{n}_{mode}"
+            if theta_obs != np.pi / 2:
+                name += "_th" + f"{theta_obs:g}".replace(".", "p")
+            name += ".npz"
+            if skip_existing and os.path.exists(os.path.join(HERE, name)):
+                continue
+            g = trace_grid(pool, kind, 1.0, a, r_obs, n, mode, theta_obs=theta_obs)
+            meta = {k: g[k] for k in ("kind", "M", "a", "r_obs", "n", "fov_deg", "refine_mode", "theta_obs")}
             save(name, meta=json.dumps(meta),
                  alpha=g["alpha"], theta=g["theta"], refine=g["refine"],
                  status=g["status"], final_alpha=g["final_alpha"],
@@ -413,12 +420,30 @@ RAY_SETS = [
     ("rk4", 0.9, 50.0, 128, "cols"),
     ("dp45", 0.9, 50.0, 128, "cols"),
     ("rk4", 0.9, 50.0, 256, "cols"),
+    # round 3: the classes the GPU frame tests exercise beyond a in {0, .5, .9, .99} and r_obs in {50, 100}
+    # (tests/test_gpu_parity.py FRAMES): spin pointing the other way, extremal spin, slow spin seen from close by,
+    # observers at 12 M and 200 M, an inclined observer (the reference's tracers take any theta_obs, metrics.py:148-218)
+    ("rk4", -0.7, 50.0, 48, "cols"),
+    ("dp45", -0.7, 50.0, 48, "cols"),
+    ("rk4", 1.0, 50.0, 48, "cols"),
+    ("dp45", 1.0, 50.0, 48, "cols"),
+    ("rk4", 0.3, 30.0, 48, "cols"),
+    ("schw", 0.0, 12.0, 48, "off"),
+    ("rk4", 0.9, 12.0, 48, "cols"),
+    ("dp45", 0.9, 12.0, 48, "cols"),
+    ("schw", 0.0, 200.0, 48, "off"),
+    ("rk4", 0.9, 200.0, 48, "cols"),
+    ("dp45", 0.9, 200.0, 48, "cols"),
+    ("rk4", 0.9, 50.0, 48, "cols", 1.0),
+    ("dp45", 0.9, 50.0, 48, "cols", 1.0),
+    ("rk4", 0.9, 300.0, 32, "cols"),
 ]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
+    ap.add_argument("--new-only", action="store_true", help="F3: only the ray sets whose file does not exist yet")
     args = ap.parse_args()
     todo = args.only.split(",") if args.only else ["F1", "F2", "F3", "F4", "F6", "F7", "F8", "F9", "F10"]
     t0 = time.time()
@@ -439,7 +464,7 @@ def main():
     if "F4" in todo:
         print("F4"); f4_lookup()
     if "F3" in todo:
-        print("F3"); f3_rays(RAY_SETS)
+        print("F3"); f3_rays(RAY_SETS, skip_existing=args.new_only)
     print(f"done in {time.time()-t0:.0f}s")
 
 

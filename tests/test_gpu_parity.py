@@ -71,7 +71,7 @@ def _trace_like(meta, g, precision, integrator):
         ltrace.trace_batch_schw(meta["M"], meta["r_obs"], g["alpha"], fa, w, precision=precision,
                                 out_status=st, out_rhs_evals=ev)
     else:
-        ltrace.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"], g["theta"], np.pi / 2,
+        ltrace.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"], g["theta"], meta.get("theta_obs", np.pi / 2),
                                 max(5000.0, 6.0 * meta["r_obs"]), g["refine"], fa, w,
                                 integrator=integrator, precision=precision, out_status=st, out_rhs_evals=ev)
     return fa, w, st, ev
@@ -263,6 +263,15 @@ def test_partitions_reassemble_bit_identically():
             assert np.array_equal(acc[k], whole[k], equal_nan=True), k
 
 
+def _reference_256():
+    """The REFERENCE's own 256 x 256 frame of the benchmark camera (Kerr a = 0.9, r_obs = 50 M, fixed-step RK4 float64,
+    axis-refine columns): per-ray outputs of _kerr_trace_ray_rk4_numba written by tests/golden/make_golden.py.  Pixel
+    (k i, k j) of a (256 k)^2 frame of the same camera is pixel (i, j) of it: same alpha, theta and refine flag."""
+    g = _load("rays_rk4_a0p9_r50_n256_cols.npz")
+    n = 256
+    return {"fa": g["final_alpha"].reshape(n, n), "status": g["status"].reshape(n, n), "evals": g["rhs_evals"].reshape(n, n)}
+
+
 def _subsample_vs_oracle(out, small, k, p99, flips_budget=66):
     sub_fa, sub_st = out["fa"][::k, ::k], out["status"][::k, ::k]
     flips = (sub_st == 1) != (small["status"] == 1)
@@ -291,7 +300,7 @@ def test_kerr_large_frame_properties(size):
     assert st["rays"] == size * size == st["escaped"] + st["captured"] + st["invalid"]
     assert st["waves"] == (size // 8) ** 2 and st["wave_iters"] >= out["steps"].max()     # the kernel's own work counters
     assert 500.0 < st["clock_mhz"] < 2600.0
-    small = oracle.lookup("kerr", 1.0, 0.9, 50.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
+    small = _reference_256()              # the reference's own per-ray outputs, not the oracle's restatement of them
     frac_small = (small["status"] != 1).mean()
     frac_big = (out["status"] != 1).mean()
     assert abs(frac_big - frac_small) < 0.02 * frac_small + 2.0 / 256
@@ -305,15 +314,16 @@ def test_kerr_large_frame_properties(size):
 
 def test_north_star_frame_4096():
     """THE benchmark frame (BASELINE.json metric: Kerr a = 0.9, 4096^2, r_obs = 50 M, fixed-step RK4 float32) at
-    full size: every 16th pixel against the oracle's 256^2 frame of the same camera (float32 budget), class
-    counts against the oracle's class fractions, and the queue schedule's counters against the direct one's."""
+    full size: every 16th pixel against the REFERENCE's 256^2 frame of the same camera (the fixture
+    rays_rk4_a0p9_r50_n256_cols.npz; float32 budget), class counts against its class fractions, and the queue
+    schedule's counters against the direct one's."""
     size = 4096
     cam = _cam(size, size, 50.0)
     met = ltrace.Metric(1, 0, 1.0, 0.9)
     out = ltrace.render(cam, met, ltrace.default_opts(precision=32), want=("fa", "status"))
     st = out["stats"]
     assert st["rays"] == size * size == st["escaped"] + st["captured"] + st["invalid"]
-    small = oracle.lookup("kerr", 1.0, 0.9, 50.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
+    small = _reference_256()              # the reference's own per-ray outputs, not the oracle's restatement of them
     _subsample_vs_oracle(out, small, 16, 5e-5)
     # class fractions are resolution independent up to the pixels the critical curve crosses (~ perimeter / area)
     for name, code in (("escaped", 1), ("captured", -1)):
@@ -371,7 +381,7 @@ def test_batch_dp45_matches_reference(name, schedule):
     n = g["alpha"].size
     fa, w = np.full(n, np.nan), np.zeros(n, dtype=np.int64)
     st, ev = np.zeros(n, dtype=np.int8), np.zeros(n, dtype=np.uint32)
-    ltrace.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"], g["theta"], np.pi / 2,
+    ltrace.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"], g["theta"], meta.get("theta_obs", np.pi / 2),
                             max(5000.0, 6.0 * meta["r_obs"]), g["refine"], fa, w, integrator="dp45",
                             precision=64, schedule=schedule, out_status=st, out_rhs_evals=ev)
     same_class = (st == 1) == (g["status"] == 1)
@@ -438,6 +448,18 @@ def test_image_lens_4096_lensed_background():
     small = oracle.lookup("kerr", 1.0, 0.9, 100.0, 256, 256, cam.hfov, cam.vfov, integrator="rk4")
     _subsample_vs_oracle(out, small, 16, 1e-4)
     assert abs(out["stats"]["steps"] / out["stats"]["rays"] - small["evals"].mean() / 4) < 0.01 * small["evals"].mean() / 4
+    # ... and every 64th pixel against the REFERENCE's own 64^2 frame of this camera (rays_rk4_a0p9_r100_n64_cols.npz)
+    g = _load("rays_rk4_a0p9_r100_n64_cols.npz")
+    ref64 = {"fa": g["final_alpha"].reshape(64, 64), "status": g["status"].reshape(64, 64)}
+    _subsample_vs_oracle(out, ref64, 64, 1e-4, flips_budget=8)
+    # the LDS-tiled background path at the full size of config 4: the same texels, bit for bit (north star: "LDS staging of
+    # the ... background-image tile"; the global gather is the default because it measures faster)
+    lds = ltrace.render(cam, ltrace.Metric(1, 0, 1.0, 0.9), ltrace.default_opts(precision=32, bg_sampling=ltrace.BG_LDS_TILES),
+                        background=bg, want=("rgb", "rgba"))
+    assert np.array_equal(lds["rgb"], out["rgb"]) and np.array_equal(lds["rgba"], out["rgba"])
+    n_tiles = (n // 16) ** 2
+    assert lds["stats"]["bg_tiles_lds"] > 0.8 * n_tiles and lds["stats"]["bg_tiles_global"] > 0
+    assert lds["stats"]["bg_tiles_lds"] + lds["stats"]["bg_tiles_global"] <= n_tiles
 
 
 def test_inclined_observer_and_grayscale_fused():
@@ -746,7 +768,7 @@ def test_batch_dp45_exact_controller_reproduces_reference_step_sequences(name):
     n = g["alpha"].size
     fa, w = np.full(n, np.nan), np.zeros(n, dtype=np.int64)
     st, ev = np.zeros(n, dtype=np.int8), np.zeros(n, dtype=np.uint32)
-    ltrace.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"], g["theta"], np.pi / 2,
+    ltrace.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"], g["theta"], meta.get("theta_obs", np.pi / 2),
                             max(5000.0, 6.0 * meta["r_obs"]), g["refine"], fa, w, integrator="dp45_exact",
                             precision=64, out_status=st, out_rhs_evals=ev)
     same_class = (st == 1) == (g["status"] == 1)

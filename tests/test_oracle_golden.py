@@ -50,8 +50,8 @@ def test_per_ray_traces_match_reference(golden_dir, name):
         fa, nh, st, ev = oracle.trace_batch_schw(meta["M"], meta["r_obs"], g["alpha"])
     else:
         fa, nh, st, ev = oracle.trace_batch_kerr(meta["M"], meta["a"], meta["r_obs"], g["alpha"],
-                                                 g["theta"], axis_refines=g["refine"],
-                                                 integrator=meta["kind"])
+                                                 g["theta"], theta_obs=meta.get("theta_obs", np.pi / 2),
+                                                 axis_refines=g["refine"], integrator=meta["kind"])
     n = fa.size
     same_status = st == g["status"]
     # chaotic near-critical rays may flip on last-bit libm differences: allow <= 1e-4 of pixels
