@@ -266,7 +266,10 @@ typedef struct lt_dense_opts {
     double max_step;     /* geodesic_tracer.py:63 (1.0)                                                 */
     int64_t max_points;  /* record capacity per track (>= 2)                                            */
     int32_t max_attempts; /* guard against a track that never ends (status -2); solve_ivp has none      */
-    int32_t reserved;
+    int32_t length_binning; /* order of the launch, never of the output: 1 = predict every track's length with a cheap
+                               loose-tolerance pass and launch the tracks of every window of 2048 longest first, so that
+                               the 64 tracks of a wavefront end together (records are byte-identical either way); -1 = caller order;
+                               0 = automatic (binned when the batch is at least twice what the chip holds at once) */
     void *stream;        /* hipStream_t; NULL = the default stream                                      */
 } lt_dense_opts;
 void lt_default_dense_opts(lt_dense_opts *o);
@@ -290,6 +293,10 @@ int lt_integrate_dense(const lt_metric *metric, const lt_dense_opts *opts, const
 int lt_integrate_dense_dev(const lt_metric *metric, const lt_dense_opts *opts, const double *d_state0, int64_t n,
                            double *d_out_t, double *d_out_y, int32_t *d_out_count, int8_t *d_out_status,
                            int32_t *d_out_nfev);
+/* Diagnostic: the keys the length-binned launch orders the tracks by -- predicted step attempts of each track,
+ * clamped to 2047 -- from the loose-tolerance predictor pass alone.  HOST pointers, out_key (n) uint16. */
+int lt_dense_predict_lengths(const lt_metric *metric, const lt_dense_opts *opts, const double *state0, int64_t n,
+                             uint16_t *out_key);
 /* Device probe of the 8-D right-hand side for parity tests: states (n, 8) -> out (n, 8), host pointers. */
 int lt_rhs8_probe(const lt_metric *metric, const double *states, int64_t n, double *out);
 

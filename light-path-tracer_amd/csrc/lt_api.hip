@@ -95,6 +95,7 @@ struct StreamSlot {
     hipStream_t stream = nullptr;
     Grow ws;     // ray records of lt_render_dev / the batch twins
     Grow dev;    // lt_render / batch twins: device-side inputs and outputs
+    Grow dense;  // lt_integrate_dense_dev, length-binned launch: histogram, cursors, keys, permutation
     Grow blocks; // block-owner table mode: this partition's block list on the device
     std::vector<int32_t> blocks_host; // what `blocks` holds (skip the upload when unchanged)
     EventQuad own{}; // lt_render's private timing events (created on first use)
@@ -226,6 +227,7 @@ extern "C" int lt_release_stream(void *stream)
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     release(found->ws);
     release(found->dev);
+    release(found->dense);
     release(found->blocks);
     if (found->own_ok) for (auto &e : found->own.e) (void)hipEventDestroy(e);
     delete found;
@@ -244,7 +246,7 @@ extern "C" int lt_shutdown(void)
         (void)hipSetDevice(d);
         (void)hipDeviceSynchronize();
         for (StreamSlot *sl : c.slots) {
-            release(sl->ws); release(sl->dev); release(sl->blocks);
+            release(sl->ws); release(sl->dev); release(sl->dense); release(sl->blocks);
             if (sl->own_ok) for (auto &e : sl->own.e) (void)hipEventDestroy(e);
             delete sl;
         }

@@ -166,9 +166,34 @@ struct DenseOut {
 // Blocks of 64 tracks are handed out from a queue head to a grid that fills the chip once, like the tiles of
 // k_kerr_direct (the XCDs run at different clocks; a workgroup per block leaves the fastest idle at the end);
 // head == nullptr: one workgroup per block.
+//
+// `perm` (nullable): slot -> track.  The length-binned launch (k_dense_predict + k_dense_window_sort below) passes the
+// tracks ordered by predicted length inside windows of a few thousand, so that the 64 tracks of a wavefront end within
+// a few attempts of each other; records, counts and endings are written at the TRACK's index either way, and a track's
+// arithmetic never depends on its neighbours, so the output is byte-identical to the launch in caller order.
+//
+// Record writes.  The kernel issues the same number of cycles with its record stores compiled out (GRBM_GUI_ACTIVE,
+// SQ_BUSY_CYCLES and SQ_WAVE_CYCLES equal to 0.3 %, tools/scratch/dense_wait_counters.sh): the stores are hidden
+// completely.  What they cost is CLOCK: with the lanes filled by the length-binned order the chip held 2.38 GHz without
+// the stores and 1.96 GHz with them (27.1 against 32.9 ms for 4 M tracks).  Measured where the bytes went: WRITE_SIZE
+// 86.8 GB per launch for 51.9 GB of records -- the 8-byte affine-parameter value of a point, stored alone, left L2 as a
+// partial line of its own nearly every time (the y-records streaming through evict it before its neighbours arrive).
+// So a lane keeps its last eight t values in LDS and writes them together: WRITE_SIZE 58.2 GB, 37.5 -> 35.4 ms on one
+// box, 37.4 -> 37.1 ms in an interleaved A/B on another: the bytes are saved, the clock barely answers.
+// Streaming (nontemporal) stores for the points: 3x slower (118 ms) -- L2 is what merges a point's four 16-byte stores.
+// (Also built and measured: parking the 64-byte y-points in LDS so that 4 / 8 / 16 neighbouring lanes write 64 / 128 /
+// 256 contiguous bytes of ONE track -- TCP_TCC_WRITE_REQ 3.59 G -> 1.44 G per launch, the address unit's stall cycles a
+// quarter -- 38.7 / 36.6 / 36.4 ms: the request count was never the limit.  Not kept.)
 __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts k, const double *__restrict__ state0, DenseOut o,
-                                                                     unsigned long long *__restrict__ head)
+                                                                     unsigned long long *__restrict__ head,
+                                                                     const int32_t *__restrict__ perm)
 {
+    __shared__ double tring[64 * 9]; // eight t values per lane (stride 9: the lanes of an LDS access fall in different banks)
+    const int lane = (int)threadIdx.x;
+    // t values are parked only in the length-binned launch, where the 64 lanes accept their steps in lockstep and write
+    // their eight values out in the same iteration; in caller order the lanes fill up at different times, every one of
+    // them then pays its own eight store instructions, and the launch is 8 % SLOWER with the ring than without (A/B on one box)
+    const bool ring = perm != nullptr;
     int64_t block = blockIdx.x;
     for (;;) {
     if (head) {
@@ -178,8 +203,9 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
                           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
     }
     if (block * 64 >= k.n) return;
-    const int64_t i = block * 64 + threadIdx.x;
-    if (i < k.n) {
+    const int64_t slot_i = block * 64 + threadIdx.x;
+    if (slot_i < k.n) {
+    const int32_t i = perm ? perm[slot_i] : (int32_t)slot_i; // (n < 2^31, checked by the host: one register, not two)
     // Dormand-Prince tableau (Dormand & Prince 1980) and Shampine's dense-output matrix
     constexpr double A21 = 1.0 / 5, A31 = 3.0 / 40, A32 = 9.0 / 40, A41 = 44.0 / 45, A42 = -56.0 / 15, A43 = 32.0 / 9,
                      A51 = 19372.0 / 6561, A52 = -25360.0 / 2187, A53 = 64448.0 / 6561, A54 = -212.0 / 729,
@@ -197,15 +223,26 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
 
     double y[8], f[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) y[c] = state0[i * 8 + c];
+    for (int c = 0; c < 8; ++c) y[c] = state0[(int64_t)i * 8 + c];
     const double r_in = k.r_in, r_out = k.r_out < 0 ? 2.0 * y[1] : k.r_out;
     double t = 0.0;
-    int32_t n_pts = 0, nfev = 0;
+    int32_t n_pts = 0, nfev = 0, nt = 0;
     int status = 0;
+    const int64_t rec0 = (int64_t)i * k.max_points; // this track's first record slot
+    auto flush_t = [&](int32_t first) { // the parked t values belong to the points first, first + 1, ...
+        for (int q = 0; q < nt; ++q) o.t[rec0 + first + q] = tring[lane * 9 + q];
+        nt = 0;
+    };
     auto push = [&](double tt, const double *yy) {
-        const int64_t slot = i * k.max_points + (n_pts < k.max_points ? n_pts : k.max_points - 1);
+        const int64_t slot = rec0 + (n_pts < k.max_points ? n_pts : k.max_points - 1);
 #ifndef LT_DENSE_NOSTORE // (diagnostic builds only: the kernel without its record stores)
-        o.t[slot] = tt;
+        if (ring && n_pts < k.max_points - 1) {
+            tring[lane * 9 + nt] = tt;
+            if (++nt == 8) flush_t(n_pts - 7);
+        } else { // the record's last slot is rewritten by every further point (it ends up holding the final one)
+            flush_t((int32_t)k.max_points - 1 - nt);
+            o.t[slot] = tt;
+        }
         double2 *rec = reinterpret_cast<double2 *>(o.y + slot * 8); // 64-byte aligned (hipMalloc'd base, 64 B per point)
 #pragma unroll
         for (int c = 0; c < 4; ++c) rec[c] = make_double2(yy[2 * c], yy[2 * c + 1]);
@@ -348,6 +385,7 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
         push(te, ye);
         status = take_in ? 1 : 2;
     }
+    flush_t((n_pts < k.max_points - 1 ? n_pts : (int32_t)k.max_points - 1) - nt);
     o.count[i] = n_pts;
     o.status[i] = (int8_t)status;
     o.nfev[i] = nfev;
@@ -355,6 +393,241 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
     if (!head) return;
     }
 }
+
+// ---- length-binned launch: predictor pass + windowed counting sort ------------------------------------------------
+// Why: one track per lane, 64 consecutive tracks per wavefront, attempts per track 126 ... 232 (5th ... 95th
+// percentile, 586 at most) bound the lane utilisation of k_dense_tracks at 0.63 (measured 0.596,
+// profiles/r02_dense_tracks.txt) -- every wave waits for its longest track.  Sorted by length the bound is 1.
+// The length is not known before the track is integrated, but it can be PREDICTED from a cheap integration of the same
+// equations: the same Dormand-Prince pair at a loose tolerance (rtol_l, atol_l = rtol_l / 100 -- the ratio of the real
+// pass, so that every component's error scale shrinks by the same factor) with a free step size.  An accepted loose
+// step of length h with error norm err tells how many steps the REAL pass takes across it: the local error of the
+// pair goes as h^5, so the real pass (tolerance ratio q = rtol / rtol_l, safety 0.9) takes steps of
+// h_t = 0.9 h (q / err)^(1/5) there, capped by max_step:  n = max(h / max_step, err^(1/5) / (0.9 q^(1/5))).
+// Summed over the track (the step that holds the terminal event counted up to the event, by linear interpolation in r):
+// correlation 0.98 with the real attempt count, utilisation bound 0.91 when sorted by it, at 16 % of the real pass's
+// attempts for rtol_l = 1e-4 (CPU twin: oracle/lt_oracle_dense.c lto_dense_step_log, tests/test_oracle_golden.py).
+// The prediction only orders the launch; no output value depends on it.
+constexpr int DENSE_KEY_BINS = 2048; // one bin per predicted attempt, the last one open-ended
+
+template <typename T> struct PredictConsts {
+    T M, a, a2, r_zero;
+    int floor_sin2;
+    T lambda_max, r_in, r_out; // r_out < 0: twice the track's start radius
+    T rtol, atol;              // of the LOOSE pass
+    T inv_step, inv_kappa;     // 1 / max_step of the real pass;  1 / (0.9 (rtol_real / rtol_loose)^(1/5))
+    int64_t n;
+    int32_t max_attempts;
+};
+
+// the 8-D right-hand side of rhs8_sc in the predictor's arithmetic (float32 by default: a tolerance of 1e-4 is far above
+// its rounding, and a float32 instruction issues at twice the rate of a float64 one)
+template <typename T> __device__ __forceinline__ void rhs8_t(const PredictConsts<T> &k, const T *y, T *d)
+{
+    const T r = y[1], E = -y[4], pr = y[5], pth = y[6], L = y[7];
+    if (r <= k.r_zero) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = T(0);
+        return;
+    }
+    T s, c;
+    M<T>::sincos(y[2], s, c);
+    T s2 = s * s;
+    s2 = M<T>::max(s2, T(1e-15)); // (the Kerr form has no floor; the predictor only needs a finite number)
+    const T r2 = r * r, ra = r2 + k.a2;
+    const T Sigma = r2 + k.a2 * c * c, Delta = ra - T(2) * k.M * r;
+    const T SD = Sigma * Delta, t = M<T>::rcp(SD * s2);
+    const T iS = (Delta * s2) * t, iD = (Sigma * s2) * t, is2 = SD * t;
+    const T P = E * ra - k.a * L, D = L - k.a * E * s2;
+    const T PD = P * iD, Ds = D * is2;
+    const T F = Delta * pr * pr + pth * pth + D * Ds - P * PD;
+    const T H2 = F * iS;
+    d[0] = (k.a * D + ra * PD) * iS;
+    d[1] = Delta * pr * iS;
+    d[2] = pth * iS;
+    d[3] = (Ds + k.a * PD) * iS;
+    d[4] = T(0);
+    d[5] = -iS * ((r - k.M) * (pr * pr + PD * PD) - r * (T(2) * E * PD + H2));
+    d[6] = iS * (s * c) * (Ds * (T(2) * k.a * E + Ds) - H2 * k.a2);
+    d[7] = T(0);
+}
+
+template <typename T> __device__ __forceinline__ T rms8_t(const T *x)
+{
+    T s = T(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i] * x[i];
+    return (T)__builtin_sqrtf((float)s) * T(0.35355339059327373);
+}
+
+// x^p for x > 0 through the hardware log2 / exp2 (relative error ~1e-6: the step controller and the prediction need no more)
+__device__ __forceinline__ float fast_pow(float x, float p) { return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)); }
+
+// One track per lane; writes the track's key (predicted attempts, clamped).
+// Blocks of 64 tracks are handed out from `head` (nullptr: block = workgroup), as in k_dense_tracks.
+template <typename T>
+__global__ void __launch_bounds__(64) k_dense_predict(PredictConsts<T> k, const double *__restrict__ state0,
+                                                      uint16_t *__restrict__ key, unsigned long long *__restrict__ head)
+{
+    constexpr T A21 = T(1.0 / 5), A31 = T(3.0 / 40), A32 = T(9.0 / 40), A41 = T(44.0 / 45), A42 = T(-56.0 / 15), A43 = T(32.0 / 9),
+                A51 = T(19372.0 / 6561), A52 = T(-25360.0 / 2187), A53 = T(64448.0 / 6561), A54 = T(-212.0 / 729),
+                A61 = T(9017.0 / 3168), A62 = T(-355.0 / 33), A63 = T(46732.0 / 5247), A64 = T(49.0 / 176), A65 = T(-5103.0 / 18656);
+    constexpr T B1 = T(35.0 / 384), B3 = T(500.0 / 1113), B4 = T(125.0 / 192), B5 = T(-2187.0 / 6784), B6 = T(11.0 / 84);
+    constexpr T E1 = T(-71.0 / 57600), E3 = T(71.0 / 16695), E4 = T(-71.0 / 1920), E5 = T(17253.0 / 339200), E6 = T(-22.0 / 525), E7 = T(1.0 / 40);
+    int64_t block = blockIdx.x;
+    for (;;) {
+        if (head) {
+            unsigned long long w = 0;
+            if (threadIdx.x == 0) w = atomicAdd(head, 1ull);
+            block = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+                              (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
+        }
+        if (block * 64 >= k.n) break;
+        const int64_t i = block * 64 + threadIdx.x;
+        if (i < k.n) {
+            T y[8], f[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) y[c] = (T)state0[i * 8 + c];
+            const T r_in = k.r_in, r_out = k.r_out < T(0) ? T(2) * y[1] : k.r_out;
+            rhs8_t(k, y, f);
+            T h;
+            { // Hairer's initial step, as the real pass (at the loose tolerance)
+                T v[8], sc[8], y1[8], f1[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { sc[c] = k.atol + M<T>::abs(y[c]) * k.rtol; v[c] = y[c] / sc[c]; }
+                T d0 = rms8_t(v);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = f[c] / sc[c];
+                T d1 = rms8_t(v);
+                T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : T(0.01) * d0 / d1;
+                h0 = M<T>::min(h0, k.lambda_max);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) y1[c] = y[c] + h0 * f[c];
+                rhs8_t(k, y1, f1);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = (f1[c] - f[c]) / sc[c];
+                T d2 = rms8_t(v) / h0;
+                T dm = M<T>::max(d1, d2);
+                T h1 = dm <= T(1e-15) ? M<T>::max(T(1e-6), h0 * T(1e-3)) : (T)fast_pow(0.01f / (float)dm, 0.2f);
+                h = M<T>::min(M<T>::min(T(100) * h0, h1), k.lambda_max);
+            }
+            T t = T(0), pred = T(0);
+            T g_in = y[1] - r_in, g_out = y[1] - r_out;
+            bool rejected = false, ended = false;
+            for (int32_t attempts = 0; attempts < k.max_attempts; ++attempts) {
+                if (!(t < k.lambda_max) || !(h > T(1e-6) * (T(1) + t))) { ended = true; break; } // (a collapsed step size: whatever was predicted so far)
+                T hh = M<T>::min(h, k.lambda_max - t);
+                T k2[8], k3[8], k4[8], k5[8], k6[8], k7[8], tmp[8], yn[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * hh;
+                rhs8_t(k, tmp, k2);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * hh;
+                rhs8_t(k, tmp, k3);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * hh;
+                rhs8_t(k, tmp, k4);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * hh;
+                rhs8_t(k, tmp, k5);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * hh;
+                rhs8_t(k, tmp, k6);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) yn[c] = y[c] + hh * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
+                rhs8_t(k, yn, k7);
+                T e[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    T ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * hh;
+                    e[c] = ec * M<T>::rcp(k.atol + M<T>::max(M<T>::abs(y[c]), M<T>::abs(yn[c])) * k.rtol);
+                }
+                const T err = rms8_t(e);
+                if (!(err < T(1))) { // rejected (or NaN): shrink, try again
+                    T fac = err == err ? (T)(0.9f * fast_pow((float)err, -0.2f)) : T(0.2);
+                    h = hh * M<T>::max(T(0.2), fac);
+                    rejected = true;
+                    continue;
+                }
+                T fac = err > T(1e-12) ? M<T>::min(T(10), (T)(0.9f * fast_pow((float)err, -0.2f))) : T(10);
+                if (rejected) fac = M<T>::min(T(1), fac);
+                rejected = false;
+                h = hh * fac;
+                const T gn_in = yn[1] - r_in, gn_out = yn[1] - r_out;
+                const bool hit_in = g_in >= T(0) && gn_in <= T(0), hit_out = g_out <= T(0) && gn_out >= T(0);
+                T used = hh;
+                if (hit_in || hit_out) { // the part of the step before the event, by linear interpolation in r
+                    T g0 = hit_in ? g_in : g_out, g1 = hit_in ? gn_in : gn_out;
+                    T fr = g0 != g1 ? g0 / (g0 - g1) : T(1);
+                    used = hh * M<T>::min(M<T>::max(fr, T(0)), T(1));
+                }
+                // steps of the real pass across this one: held by max_step, or by the tolerance
+                const T by_tol = err > T(1e-12) ? (T)fast_pow((float)err, 0.2f) * k.inv_kappa * (used / hh) : T(0);
+                pred += M<T>::max(used * k.inv_step, by_tol);
+                if (hit_in || hit_out) { ended = true; break; }
+                g_in = gn_in; g_out = gn_out;
+                t += hh;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { y[c] = yn[c]; f[c] = k7[c]; }
+            }
+            // a track the loose pass did not finish within its attempt budget (a photon that orbits the hole for long: a few
+            // per cent of a fan of rays, several times the typical effort) is long: it goes first in its window
+            if (!ended) pred = T(DENSE_KEY_BINS);
+            int kk = pred == pred ? (int)(float)pred : 0;
+            kk = kk < 0 ? 0 : (kk > DENSE_KEY_BINS - 1 ? DENSE_KEY_BINS - 1 : kk);
+            key[i] = (uint16_t)kk;
+        }
+        if (!head) break;
+    }
+}
+
+#ifndef LT_KERNEL_TEMPLATES_ONLY
+// perm: inside every WINDOW of `window` consecutive tracks, the tracks by descending key; windows stay in caller order.
+// Why windows and not one global order: a lane appends to ITS track's record, so the 64 lanes of a wavefront write 64
+// different places for the whole life of the wave.  In caller order those are 64 neighbouring records (one or two
+// pages); in a global longest-first order they are 64 random places of a record buffer of tens of GB -- measured at 4 M
+// tracks (67 GB of records): the stores, 1.9 ms of the launch in caller order, cost 8.5 ms, all that the sort had won
+// (address translation: every store instruction then touches 64 pages no other wave shares).  Within a window of 2 048
+// tracks (29 MB of records) a wave's lanes stay within a few pages, and sorting inside windows keeps nearly all of the
+// gain: the utilisation bound of one track per lane is 0.90 for windows of 2 048 against 0.92 for the global order.
+// One workgroup per window: histogram of the keys in LDS, prefix over the bins from the top, scatter -- no global
+// atomics, no second kernel.  The order inside a bin is whatever the LDS atomics made it; it does not matter.
+__global__ void __launch_bounds__(256) k_dense_window_sort(const uint16_t *__restrict__ key, int32_t *__restrict__ perm,
+                                                           int64_t n, int window)
+{
+    __shared__ uint32_t cnt[DENSE_KEY_BINS];
+    __shared__ uint32_t part[256];
+    const int t = threadIdx.x;
+    for (int b = t; b < DENSE_KEY_BINS; b += 256) cnt[b] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * window;
+    const int64_t end = base + window < n ? base + window : n;
+    for (int64_t i = base + t; i < end; i += 256) atomicAdd(&cnt[key[i]], 1u);
+    __syncthreads();
+    // exclusive prefix over the bins from the top: thread t owns the bins [hi - PER + 1, hi], hi = BINS - 1 - t * PER
+    constexpr int PER = DENSE_KEY_BINS / 256;
+    const int hi = DENSE_KEY_BINS - 1 - t * PER;
+    uint32_t own[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { own[j] = cnt[hi - j]; sum += own[j]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { cnt[hi - j] = run; run += own[j]; }
+    __syncthreads();
+    for (int64_t i = base + t; i < end; i += 256) {
+        const uint32_t pos = atomicAdd(&cnt[key[i]], 1u);
+        perm[base + pos] = (int32_t)i; // pos < end - base: the bins hold exactly the window's tracks
+    }
+}
+#endif // LT_KERNEL_TEMPLATES_ONLY
 
 // probe of rhs8 for the parity tests
 __global__ void __launch_bounds__(64) k_rhs8_probe(DenseConsts k, const double *__restrict__ states, double *__restrict__ out)

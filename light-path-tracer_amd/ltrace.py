@@ -58,7 +58,7 @@ BG_LDS_TILES, BG_GLOBAL = 0, 1
 class DenseOpts(C.Structure):
     _fields_ = [("lambda_max", C.c_double), ("r_stop_inner", C.c_double), ("r_stop_outer", C.c_double),
                 ("rtol", C.c_double), ("atol", C.c_double), ("max_step", C.c_double),
-                ("max_points", C.c_int64), ("max_attempts", C.c_int32), ("reserved", C.c_int32),
+                ("max_points", C.c_int64), ("max_attempts", C.c_int32), ("length_binning", C.c_int32),
                 ("stream", C.c_void_p)]
 
 
@@ -114,6 +114,7 @@ SIGNATURES = {
     "lt_integrate_dense_dev": (C.c_int, [C.POINTER(Metric), C.POINTER(DenseOpts), C.c_void_p, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lt_rhs8_probe": (C.c_int, [C.POINTER(Metric), C.c_void_p, C.c_int64, C.c_void_p]),
+    "lt_dense_predict_lengths": (C.c_int, [C.POINTER(Metric), C.POINTER(DenseOpts), C.c_void_p, C.c_int64, C.c_void_p]),
 }
 
 
@@ -441,6 +442,15 @@ def integrate_dense_dev(metric, opts, d_state0, n, d_t, d_y, d_count, d_status, 
     _check(load().lt_integrate_dense_dev(C.byref(metric), C.byref(opts), C.c_void_p(d_state0), n, C.c_void_p(d_t),
                                          C.c_void_p(d_y), C.c_void_p(d_count), C.c_void_p(d_status),
                                          C.c_void_p(d_nfev)))
+
+
+def dense_predict_lengths(metric, state0, opts=None):
+    """Predicted step attempts per track (uint16, clamped to 2047): what the length-binned dense launch sorts by."""
+    o = opts or default_dense_opts()
+    s0 = np.ascontiguousarray(state0, dtype=np.float64).reshape(-1, 8)
+    key = np.zeros(s0.shape[0], dtype=np.uint16)
+    _check(load().lt_dense_predict_lengths(C.byref(metric), C.byref(o), _np_ptr(s0), s0.shape[0], _np_ptr(key)))
+    return key
 
 
 def rhs8_probe(metric, states):

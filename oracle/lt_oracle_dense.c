@@ -201,6 +201,11 @@ static double brent_root(const EvCtx *c, double xa, double xb)
  * max_points are stored, the LAST stored slot always holding the final point).
  * status: 1 capture event, 2 escape event, 0 lambda_max reached, -1 step size underflow.
  */
+/* Optional per-step log (accepted steps only): step length and the error norm it was accepted with.  Used by
+ * lto_predict_attempts below -- the CPU twin of the dense kernel's length predictor -- and never by the record path. */
+static __thread double *g_step_h = NULL, *g_step_err = NULL;
+static __thread int64_t g_step_cap = 0, g_step_n = 0;
+
 int64_t lto_integrate_dense(int kind, double M, double a, const double *state0, double lambda_max, double r_stop_inner,
                             double r_stop_outer, double rtol, double atol, double max_step, int64_t max_points,
                             double *out_t, double *out_y, int *out_status, int64_t *out_nfev)
@@ -275,6 +280,8 @@ int64_t lto_integrate_dense(int kind, double M, double a, const double *state0, 
             }
             double err = rms8(e);
             if (err < 1) {
+                if (g_step_h && g_step_n < g_step_cap) { g_step_h[g_step_n] = h; g_step_err[g_step_n] = err; }
+                ++g_step_n;
                 double factor = (err == 0) ? 10 : fmin(10, 0.9 * pow(err, -0.2));
                 if (rejected) factor = fmin(1, factor);
                 h_abs *= factor;
@@ -314,5 +321,27 @@ done:
 #undef PUSH
     *out_status = status;
     *out_nfev = S.nfev;
+    return n;
+}
+
+/* One track through the integrator above at a LOOSE tolerance with a free step size, logging (h, err) of every
+ * accepted step: the raw material of the length predictor (lt_dense.hpp, k_dense_predict).  Returns the number of
+ * accepted steps; out_h / out_err hold the first `cap` of them. */
+int64_t lto_dense_step_log(int kind, double M, double a, const double *state0, double lambda_max, double r_stop_inner,
+                           double r_stop_outer, double rtol, double atol, double max_step, int64_t cap, double *out_h,
+                           double *out_err, int *out_status, int64_t *out_nfev)
+{
+    double t2[2], y2[16];
+    g_step_h = out_h; g_step_err = out_err; g_step_cap = cap; g_step_n = 0;
+    lto_integrate_dense(kind, M, a, state0, lambda_max, r_stop_inner, r_stop_outer, rtol, atol, max_step, 2, t2, y2, out_status,
+                        out_nfev);
+    int64_t n = g_step_n;
+    g_step_h = g_step_err = NULL; g_step_cap = 0; g_step_n = 0;
+    /* the step that contains the terminal event is used up to the event only */
+    if (n > 0 && n <= cap && *out_status > 0) {
+        double before = 0;
+        for (int64_t i = 0; i + 1 < n; ++i) before += out_h[i];
+        out_h[n - 1] = t2[1] - before;
+    }
     return n;
 }

@@ -70,6 +70,9 @@ def lib():
         L.lto_integrate_dense.argtypes = [C.c_int, C.c_double, C.c_double, _dp] + [C.c_double] * 6 + [
             C.c_int64, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
         L.lto_integrate_dense.restype = C.c_int64
+        L.lto_dense_step_log.argtypes = [C.c_int, C.c_double, C.c_double, _dp] + [C.c_double] * 6 + [
+            C.c_int64, _dp, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.lto_dense_step_log.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -263,3 +266,22 @@ def integrate_dense(kind, M, a, state0, lambda_max=1000.0, r_stop_inner=None, r_
                                   _ptr(t, _dp), _ptr(y, _dp), C.byref(st), C.byref(nfev))
     m = min(int(n), max_points)
     return t[:m].copy(), y[:, :m].copy(), int(st.value), int(nfev.value)
+
+
+def dense_predict_length(kind, M, a, state0, lambda_max=1000.0, r_stop_inner=None, r_stop_outer=None,
+                         rtol=1e-8, atol=1e-10, max_step=1.0, rtol_loose=1e-4):
+    """CPU twin of the dense kernel's length predictor (csrc/lt_dense.hpp, k_dense_predict): the same integrator at a loose
+    tolerance with a free step size; every accepted step of length h and error norm err stands for
+    max(h / max_step, err^(1/5) / (0.9 (rtol / rtol_loose)^(1/5))) steps of the real pass (the step holding the terminal
+    event counted up to the event).  -> (predicted attempts, attempts of the loose pass)."""
+    s0 = np.ascontiguousarray(state0, dtype=np.float64)
+    cap = 4096
+    h, e = np.empty(cap), np.empty(cap)
+    st, nfev = C.c_int(0), C.c_int64(0)
+    n = lib().lto_dense_step_log(int(kind), float(M), float(a), _ptr(s0, _dp), float(lambda_max), float(r_stop_inner),
+                                 float(r_stop_outer), float(rtol_loose), float(rtol_loose * atol / rtol), 1e300, cap,
+                                 _ptr(h, _dp), _ptr(e, _dp), C.byref(st), C.byref(nfev))
+    n = min(int(n), cap)
+    kappa = 0.9 * (rtol / rtol_loose) ** 0.2
+    pred = np.maximum(h[:n] / max_step, np.maximum(e[:n], 0.0) ** 0.2 / kappa).sum()
+    return float(pred), (int(nfev.value) - 2) // 6

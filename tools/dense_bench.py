@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Throughput of the batched dense-trajectory kernel (lt_integrate_dense_dev) on one GPU.
 
-usage: dense_bench.py [n_tracks] [max_points] [a]      (defaults 1048576 256 0.9)
+usage: dense_bench.py [n_tracks] [max_points] [a] [binning]      (defaults 1048576 256 0.9 0;
+       binning = lt_dense_opts.length_binning: 0 automatic, 1 predictor pass + longest-first launch, -1 caller order)
 
 Workload: Kerr, observer at r = 50 M, viewing angles uniform in [0.01, 0.4] rad, screen angles uniform in
 [0, 2 pi), the reference's solve_ivp settings (rtol 1e-8, atol 1e-10, max_step 1).  Initial states are built
@@ -49,6 +50,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
     mp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     a = float(sys.argv[3]) if len(sys.argv) > 3 else 0.9
+    binning = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     dev = torch.device("cuda:0")
     s0 = torch.from_numpy(states(n, a)).to(dev)
     t = torch.empty((n, mp), dtype=torch.float64, device=dev)
@@ -57,7 +59,7 @@ def main():
     st = torch.zeros(n, dtype=torch.int8, device=dev)
     nf = torch.zeros(n, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream()
-    o = ltrace.default_dense_opts(max_points=mp, stream=stream.cuda_stream)
+    o = ltrace.default_dense_opts(max_points=mp, stream=stream.cuda_stream, length_binning=binning)
     met = ltrace.Metric(ltrace.METRIC_KERR, 0, 1.0, a)
     run = lambda: ltrace.integrate_dense_dev(met, o, s0.data_ptr(), n, t.data_ptr(), y.data_ptr(), cnt.data_ptr(),
                                              st.data_ptr(), nf.data_ptr())
@@ -73,7 +75,7 @@ def main():
     pts_full = int(cnt.sum()); evals = int(nf.sum())
     attempts = (evals - 2 * n) / 6
     flops = evals * F_RHS + attempts * F_ATTEMPT
-    print(json.dumps(dict(workload=f"dense tracks Kerr a={a} r_obs=50, n={n}, max_points={mp}", ms=round(ms, 3),
+    print(json.dumps(dict(workload=f"dense tracks Kerr a={a} r_obs=50, n={n}, max_points={mp}", length_binning=binning, ms=round(ms, 3),
                           tracks_per_s=round(n / ms * 1e3), points_per_s=round(pts / ms * 1e3),
                           points_per_track=round(pts_full / n, 1), truncated=int((cnt > mp).sum()),
                           rhs_evals_per_track=round(evals / n, 1), rejected_frac=round(1 - (pts_full - n) / attempts, 4),
