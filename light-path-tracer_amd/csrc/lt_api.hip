@@ -160,9 +160,11 @@ static void release(Grow &g)
     g.bytes = 0;
 }
 
-// Workspace layout: 256 B of control words (queue head) | ic[n_q] | fin0[n_q] | fin1[n_q], each a
-// 4-vector of T.
-struct Workspace { unsigned long long *head; void *ic, *fin0, *fin1; };
+// Workspace layout: 256 B of control words (queue head) | STAT_SLOTS x 8 partial counters of the epilogue | ic[n_q] |
+// fin0[n_q] | fin1[n_q], each a 4-vector of T.  The partial counters are zero between frames (zeroed when the buffer
+// is allocated, and again by k_stats_reduce after it has read them).
+constexpr size_t WS_CTRL_BYTES = 256 + (size_t)STAT_SLOTS * 8 * sizeof(unsigned long long);
+struct Workspace { unsigned long long *head; unsigned long long *partials; void *ic, *fin0, *fin1; };
 
 static int get_workspace(hipStream_t stream, size_t n_q, size_t elem, Workspace *w)
 {
@@ -170,12 +172,15 @@ static int get_workspace(hipStream_t stream, size_t n_q, size_t elem, Workspace 
     int rc = get_slot(stream, &sl);
     if (rc) return rc;
     size_t vec = 4 * elem;
-    if ((rc = grow(sl->ws, 256 + 3 * n_q * vec, stream))) return rc;
+    const void *before = sl->ws.p;
+    if ((rc = grow(sl->ws, WS_CTRL_BYTES + 3 * n_q * vec, stream))) return rc;
+    if (sl->ws.p != before) HIP_TRY(hipMemsetAsync(sl->ws.p, 0, WS_CTRL_BYTES, stream)); // a new buffer: control words and partial counters start at zero
     char *base = (char *)sl->ws.p;
     w->head = (unsigned long long *)base;
-    w->ic = base + 256;
-    w->fin0 = base + 256 + n_q * vec;
-    w->fin1 = base + 256 + 2 * n_q * vec;
+    w->partials = (unsigned long long *)(base + 256);
+    w->ic = base + WS_CTRL_BYTES;
+    w->fin0 = base + WS_CTRL_BYTES + n_q * vec;
+    w->fin1 = base + WS_CTRL_BYTES + 2 * n_q * vec;
     return LT_OK;
 }
 
@@ -760,10 +765,10 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     Timer tm;
     if ((rc = tm.begin(o.timing != 0, own_events))) return rc;
     unsigned gq = (unsigned)((n_q + 255) / 256);
-    int64_t n_pix = (int64_t)c.rows_local * c.W;
-    unsigned gp = (unsigned)((n_pix + 255) / 256);
-    if (gp > 4096) gp = 4096; // grid-stride: 16 blocks per CU, one stats flush per block
-    FrameOut fo{d_bg, bg_channels, d_fa, d_w, d_status, d_steps, d_rgb, d_rgba, d_stats};
+    unsigned gp = 0;
+    // the epilogue adds its counters into STAT_SLOTS partial sets (workgroup index mod STAT_SLOTS) of the workspace; one
+    // small launch behind it folds them into the caller's counters
+    FrameOut fo{d_bg, bg_channels, d_fa, d_w, d_status, d_steps, d_rgb, d_rgba, d_stats ? (uint64_t *)w.partials : nullptr};
 
     if ((rc = tm.mark(0, s))) return rc;
     if (o.precision == 32) k_prologue_camera<float><<<gq, 256, 0, s>>>(c, mc, (float4 *)ic, n_q);
@@ -778,13 +783,22 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     const bool lds_path = o.bg_sampling == LT_BG_LDS_TILES && d_bg && (d_rgb || d_rgba);
     if (lds_path) {
         int64_t n16 = (int64_t)((c.W + 15) / 16) * ((c.rows_local + 15) / 16);
-        gp = (unsigned)(n16 < 4096 ? n16 : 4096);
+        gp = (unsigned)n16; // one 16x16 tile per workgroup
         if (o.precision == 32) k_epilogue_frame_lds<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
         else k_epilogue_frame_lds<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
     } else {
-        if (o.precision == 32) k_epilogue_frame<float><<<gp, 256, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
-        else k_epilogue_frame<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+        const bool has_bg = d_bg != nullptr && (d_rgb || d_rgba);
+        if (c.rows_local > 65535) return fail(LT_ERR_UNSUPPORTED, "a partition of %d rows exceeds the launch grid (65535 rows)", c.rows_local);
+        const dim3 ge((unsigned)((c.W + EPILOGUE_BLOCK - 1) / EPILOGUE_BLOCK), (unsigned)c.rows_local);
+        if (o.precision == 32) {
+            if (has_bg) k_epilogue_frame<float, true><<<ge, EPILOGUE_BLOCK, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
+            else k_epilogue_frame<float, false><<<ge, EPILOGUE_BLOCK, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);
+        } else {
+            if (has_bg) k_epilogue_frame<double, true><<<ge, EPILOGUE_BLOCK, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+            else k_epilogue_frame<double, false><<<ge, EPILOGUE_BLOCK, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
+        }
     }
+    if (d_stats) k_stats_reduce<<<1, STAT_SLOTS, 0, s>>>(w.partials, (unsigned long long *)d_stats);
     HIP_TRY(hipGetLastError());
     if ((rc = tm.mark(3, s))) return rc;
     tm.finish();

@@ -167,7 +167,10 @@ __device__ __forceinline__ void pixel_angles(const CamConsts &c, int ix, int gro
     double cos_alpha = ((x_cam * c.d[0]) + (y_cam * c.d[1]) + c.d[2]) / denom;
     cos_alpha = fmin(fmax(cos_alpha, -1.0), 1.0);
     alpha = (double)(float)acos(cos_alpha);
-    double vx = x_cam / denom, vy = y_cam / denom, vz = 1.0 / denom;
+    // (the screen angle is the atan2 of two projections of the SAME unit vector: their common factor 1 / denom cancels in
+    // the quotient, so one reciprocal -- within an ulp -- stands for the reference's three divisions; theta moves by ~1e-16)
+    const double id = M<double>::rcp_pos(denom);
+    double vx = x_cam * id, vy = y_cam * id, vz = id;
     theta = atan2(vx * c.ex[0] + vy * c.ex[1] + vz * c.ex[2], vx * c.ey[0] + vy * c.ey[1] + vz * c.ey[2]);
 }
 
@@ -178,8 +181,11 @@ __device__ __forceinline__ bool kerr_initial_momenta(const MetricConsts &m, doub
     double r = m.r_obs, a = m.a;
     p_r = p_theta = p_phi = 0.0;
     if (!m.obs_ok) return false;
-    double sin_alpha = sin(alpha), sin_screen, cos_screen;
-    sincos(theta, &sin_screen, &cos_screen);
+    // (sincos_f64: branch-free reduction + the fdlibm kernels, < 1 ulp, for angles of a few radians; OCML's carry a
+    // large-argument path)
+    double sin_alpha, cos_alpha_unused, sin_screen, cos_screen;
+    sincos_f64(alpha, sin_alpha, cos_alpha_unused);
+    sincos_f64(theta, sin_screen, cos_screen);
     double rho = r * sin_alpha * m.obs_sqrt_Sigma / m.obs_sqrt_Delta;
     double alpha_screen = -rho * sin_screen, beta_screen = -rho * cos_screen;
     double xi = -alpha_screen * m.obs_sin_th;
@@ -593,19 +599,21 @@ __global__ void __launch_bounds__(256) k_schw_rk4_direct(SchwConsts<T> k, const 
 }
 
 // ---- K3: epilogue -----------------------------------------------------------------------------
-// int(abs(phi) // pi) with Python's float floor-division (metrics.py:133, :372).
+// int(abs(phi) // pi) with Python's float floor-division (metrics.py:133, :372).  Python forms it from the EXACT
+// remainder (fmod), so the result is floor of the exact real quotient |phi| / PI of the two doubles -- an integer
+// that can be had without fmod's long division: a candidate q from one multiplication is off by at most one, and
+// the sign of r = fma(-q, PI, |phi|) -- the exact residual rounded once, so its sign and its order relative to PI
+// are the exact ones -- says which way.  (|phi| < 2^50: beyond that the candidate could be off by more; a ray winds
+// a few times.)  OCML's fmod was a fifth of the epilogue's instructions.
 __device__ __forceinline__ long long half_orbits(double phi)
 {
-    const double PI = 3.141592653589793;
-    double a = fabs(phi);
-    double mod = fmod(a, PI);
-    double div = (a - mod) / PI;
-    double fl = 0.0;
-    if (div != 0.0) {
-        fl = floor(div);
-        if (div - fl > 0.5) fl += 1.0;
-    }
-    return (long long)fl;
+    const double PI = 3.141592653589793, INV_PI = 0.3183098861837907;
+    const double a = fabs(phi);
+    if (!(a < 1e15)) return 0; // NaN / inf / absurd (never a valid ray: kerr_extract drops a non-finite final state)
+    double q = floor(a * INV_PI);
+    const double r = __builtin_fma(-q, PI, a);
+    q = r < 0.0 ? q - 1.0 : (r >= PI ? q + 1.0 : q);
+    return (long long)q;
 }
 
 struct RayResult {
@@ -615,7 +623,12 @@ struct RayResult {
     uint32_t steps, evals;
 };
 
-// _kerr_extract_angle, metrics.py:363-416 (float64, as written).
+// _kerr_extract_angle, metrics.py:363-416, float64.  Same quantities in the same order; what differs from a literal
+// transcription is the cost of three library calls: sin / cos of the two final angles come from sincos_f64 (branch-free
+// Cody-Waite + the fdlibm kernels, < 1 ulp; OCML's sincos carries a Payne-Hanek path for arguments a ray never has), the
+// four quotients by Sigma, Delta, Sigma Delta and Sigma Delta sin^2 from ONE reciprocal of their common denominator
+// (rcp_pos: hardware seed + two Newton steps, within an ulp), the normalisation of the exit direction from a reciprocal
+// of |v|.  final_alpha moves by a few 1e-16 (the budgets of the parity tests are 1e-10 and up; it is stored as float32).
 __device__ __forceinline__ void kerr_extract(const MetricConsts &m, double r_f, double th_f, double phi_f,
                                              double p_r_f, double p_th_f, double p_phi, int ev, RayResult &o)
 {
@@ -626,27 +639,30 @@ __device__ __forceinline__ void kerr_extract(const MetricConsts &m, double r_f, 
     if (r_f <= m.r_capture * 1.1 || ev == EV_CAPTURED) { o.status = -1; return; }
     if (!isfinite(r_f) || !isfinite(th_f) || !isfinite(phi_f)) { o.status = 0; o.n_half = 0; return; }
     double a = m.a, M_ = m.M, p_t = -1.0;
-    double sin_th, cos_th;
-    sincos(th_f, &sin_th, &cos_th);
+    // (sincos_f64's reduction is good to |x| ~ 1e5; a ray's angles are a few multiples of pi -- lambda_max bounds them)
+    double sin_th, cos_th, sin_phi, cos_phi;
+    sincos_f64(th_f, sin_th, cos_th);
+    sincos_f64(phi_f, sin_phi, cos_phi);
     double sin_th_sq = sin_th * sin_th;
     if (sin_th_sq < 1e-15) sin_th_sq = 1e-15;
     double Sigma_f = r_f * r_f + a * a * cos_th * cos_th;
     double Delta_f = r_f * r_f - 2.0 * M_ * r_f + a * a;
     if (Sigma_f <= 1e-15 || fabs(Delta_f) <= 1e-15) { o.status = 0; return; }
-    double dr_dl = Delta_f / Sigma_f * p_r_f;
-    double dth_dl = p_th_f / Sigma_f;
-    double dphi_dl = (-2.0 * M_ * a * r_f / (Sigma_f * Delta_f) * p_t
-                      + (Delta_f - a * a * sin_th_sq) / (Sigma_f * Delta_f * sin_th_sq) * p_phi);
-    double sin_phi, cos_phi;
-    sincos(phi_f, &sin_phi, &cos_phi);
+    // r_f > 1.1 r_capture > r_plus: Delta > 0, Sigma > 0, sin^2 >= 1e-15 -- the common denominator is a positive normal number
+    const double SD = Sigma_f * Delta_f;
+    const double t = M<double>::rcp_pos(SD * sin_th_sq);
+    const double iS = (Delta_f * sin_th_sq) * t, iSD = sin_th_sq * t, iSDs = t; // 1/Sigma, 1/(Sigma Delta), 1/(Sigma Delta sin^2)
+    double dr_dl = (Delta_f * iS) * p_r_f;
+    double dth_dl = p_th_f * iS;
+    double dphi_dl = (-2.0 * M_ * a * r_f * iSD * p_t + (Delta_f - a * a * sin_th_sq) * iSDs * p_phi);
     double vx = sin_th * cos_phi * dr_dl + r_f * cos_th * cos_phi * dth_dl - r_f * sin_th * sin_phi * dphi_dl;
     double vy = sin_th * sin_phi * dr_dl + r_f * cos_th * sin_phi * dth_dl + r_f * sin_th * cos_phi * dphi_dl;
     double vz = cos_th * dr_dl - r_f * sin_th * dth_dl;
     if (!isfinite(vx) || !isfinite(vy) || !isfinite(vz)) { o.status = 0; return; }
-    double v_mag = sqrt(vx * vx + vy * vy + vz * vz);
+    double v_mag = __builtin_sqrt(vx * vx + vy * vy + vz * vz);
     o.status = 1;
     if (v_mag < 1e-30) return;
-    o.fa = acos(fmin(fmax(-vx / v_mag, -1.0), 1.0));
+    o.fa = acos(fmin(fmax(-vx * M<double>::rcp_pos(v_mag), -1.0), 1.0));
 }
 
 // _schwarzschild_trace_ray_numba tail, metrics.py:129-145.
@@ -689,30 +705,61 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
-// Per-thread counters, reduced once per block: wave shuffle -> LDS -> six global atomics per
-// block (a first version issued them per wave and the epilogue ran at the atomic rate).
+// Per-thread counters, reduced once per block: wave level -> LDS -> a few global atomics per block (a first version
+// issued them per wave and the epilogue ran at the atomic rate).  The wave level is four ballots (a ray is counted, is
+// escaped, captured or invalid: population counts) and ONE 32-bit shuffle sum (steps); the right-hand-side evaluations
+// follow from the steps (evals_fixed per ray + evals_per_step per step, exactly).  Six 64-bit shuffle sums were a
+// quarter of the kernel's instructions.
 struct StatAcc {
-    unsigned long long rays = 0, steps = 0, evals = 0, esc = 0, cap = 0, inv = 0;
+    uint32_t steps = 0;
+    bool counted = false, esc = false, cap = false, inv = false; // this work-item's one ray
     __device__ __forceinline__ void add(const RayResult &o)
     {
-        rays += 1; steps += o.steps; evals += o.evals;
-        esc += o.status == 1; cap += o.status == -1; inv += o.status == 0;
+        counted = true; steps = o.steps;
+        esc = o.status == 1; cap = o.status == -1; inv = o.status == 0;
     }
 };
 
-__device__ __forceinline__ void flush_stats(uint64_t *stats, const StatAcc &a)
+// `stats` here is the workspace's array of STAT_SLOTS partial counter sets (8 words each): a workgroup adds into set
+// (its index mod STAT_SLOTS).  Measured at 4096^2 with one set: 32 768 workgroups x ~5 atomics on five addresses cost
+// 0.21 ms of a 0.43 ms epilogue (the L2 serialises same-address atomics); spread over 64 sets they cost nothing
+// measurable.  k_stats_reduce folds the sets into the caller's counters and zeroes them for the next frame.
+constexpr int STAT_SLOTS = 64;
+
+__device__ __forceinline__ void flush_stats(uint64_t *stats, const StatAcc &a, const MetricConsts &m)
 {
     if (!stats) return;
     __shared__ unsigned long long sh[6];
     if (threadIdx.x < 6) sh[threadIdx.x] = 0;
     __syncthreads();
-    unsigned long long v[6] = {wave_sum(a.rays), wave_sum(a.steps), wave_sum(a.evals),
-                               wave_sum(a.esc), wave_sum(a.cap), wave_sum(a.inv)};
+    uint32_t st = a.counted ? a.steps : 0u;
+    for (int off = 32; off > 0; off >>= 1) st += __shfl_xor(st, off, 64); // (<= 64 x 200 000 steps: fits)
+    const unsigned long long rays = (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(a.counted));
+    const unsigned long long v[6] = {rays, st, rays * (unsigned long long)m.evals_fixed + (unsigned long long)st * (unsigned long long)m.evals_per_step,
+                                     (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(a.esc)),
+                                     (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(a.cap)),
+                                     (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(a.inv))};
     if ((threadIdx.x & 63) == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&sh[i], v[i]);
+        for (int i = 0; i < 6; ++i) if (v[i]) atomicAdd(&sh[i], v[i]);
     __syncthreads();
-    if (threadIdx.x < 6 && sh[threadIdx.x]) atomicAdd((unsigned long long *)&stats[threadIdx.x], sh[threadIdx.x]);
+    unsigned long long *set = (unsigned long long *)stats + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) % STAT_SLOTS) * 8;
+    if (threadIdx.x < 6 && sh[threadIdx.x]) atomicAdd(&set[threadIdx.x], sh[threadIdx.x]);
 }
+
+#ifndef LT_KERNEL_TEMPLATES_ONLY
+// one wavefront: lane l holds set l; six wave sums; lane 0 adds them to the caller's counters; the sets go back to zero
+__global__ void __launch_bounds__(STAT_SLOTS) k_stats_reduce(unsigned long long *__restrict__ partials, unsigned long long *__restrict__ stats)
+{
+    unsigned long long *set = partials + (size_t)threadIdx.x * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        unsigned long long v = wave_sum(set[i]);
+        set[i] = 0;
+        const int dst = i < 6 ? i : i + 4; // 6, 7: tiles staged in LDS / served by the global gather (LT_STAT_BG_TILES_*)
+        if (threadIdx.x == 0 && v) atomicAdd(&stats[dst], v);
+    }
+}
+#endif
 
 struct FrameOut {
     const float *bg; int bg_c;
@@ -723,10 +770,13 @@ struct FrameOut {
 // Colour of one pixel, render_lensed_image (image_lens.py:296-397); rgb[3] float32.
 // shade_source decides everything except the texel read: returns true if the pixel shows the background texel
 // (sx, sy), false if its colour is already in rgb (black, winding colour, white in shadow mode, magenta).
+// HAS_BG = false: the caller knows there is no background (shadow render) -- the projection onto the source image is
+// not even compiled in, which is what lets the shadow epilogue keep its registers (k_epilogue_frame).
+template <bool HAS_BG = true>
 __device__ __forceinline__ bool shade_source(const CamConsts &c, const FrameOut &o, int ix, int grow, float fa32,
                                              int winding, float *rgb, int &nch, int &sx_out, int &sy_out)
 {
-    nch = o.bg ? o.bg_c : 3;
+    nch = (HAS_BG && o.bg) ? o.bg_c : 3;
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     sx_out = sy_out = 0;
     if (!isfinite(fa32)) return false;
@@ -738,7 +788,7 @@ __device__ __forceinline__ bool shade_source(const CamConsts &c, const FrameOut 
         else { rgb[0] = wc[idx][0]; rgb[1] = wc[idx][1]; rgb[2] = wc[idx][2]; }
         return false;
     }
-    if (!o.bg) { rgb[0] = rgb[1] = rgb[2] = 1.0f; return false; } // shadow mode: escaped = white
+    if (!HAS_BG || !o.bg) { rgb[0] = rgb[1] = rgb[2] = 1.0f; return false; } // shadow mode: escaped = white
     double x_cam = ((double)ix - c.half_W) / c.fx;
     double y_cam = ((double)grow - c.half_H) / c.fy;
     double denom = sqrt(1.0 + x_cam * x_cam + y_cam * y_cam);
@@ -773,11 +823,12 @@ __device__ __forceinline__ bool shade_source(const CamConsts &c, const FrameOut 
     return false;
 }
 
+template <bool HAS_BG = true>
 __device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int ix, int grow, float fa32,
                                       int winding, float *rgb, int &nch)
 {
     int sx, sy;
-    if (shade_source(c, o, ix, grow, fa32, winding, rgb, nch, sx, sy)) {
+    if (shade_source<HAS_BG>(c, o, ix, grow, fa32, winding, rgb, nch, sx, sy)) {
 #ifdef LT_DEBUG_NOFETCH // diagnostic build only: everything but the texel read (prices the gather itself)
         rgb[0] = (float)sx * 1e-9f; rgb[1] = (float)sy * 1e-9f; rgb[2] = 0.0f;
 #else
@@ -788,17 +839,23 @@ __device__ __forceinline__ void shade(const CamConsts &c, const FrameOut &o, int
     }
 }
 
-// Grid-stride over the partition's pixels in row-major order: every output array is written fully
-// coalesced whatever order the integrate kernel finished the rays in.
-template <typename T>
-__global__ void __launch_bounds__(256, 3) k_epilogue_frame(CamConsts c, MetricConsts m,
-                                                        const typename Vec4<T>::type *__restrict__ fin0,
-                                                        const typename Vec4<T>::type *__restrict__ fin1, FrameOut o)
+// One pixel per work-item, the partition's pixels in row-major order: every output array is written fully coalesced
+// whatever order the integrate kernel finished the rays in.  (Rounds 1-2 ran a grid-stride loop over 4 096 workgroups to
+// keep the counters' atomics few; inside the loop the compiler held 166 registers -- three waves per SIMD -- for a body
+// that needs ~65 on its own (k_epilogue_arrays): every 64-bit literal of the polynomials was hoisted out of the loop
+// into a register pair.  512 work-items per group, one flush per group into one of STAT_SLOTS counter sets.)
+// HAS_BG = false (shadow render: no background to lens) leaves the projection onto the source image out of the kernel.
+constexpr int EPILOGUE_BLOCK = 512;
+template <typename T, bool HAS_BG>
+__global__ void __launch_bounds__(EPILOGUE_BLOCK) k_epilogue_frame(CamConsts c, MetricConsts m,
+                                                                   const typename Vec4<T>::type *__restrict__ fin0,
+                                                                   const typename Vec4<T>::type *__restrict__ fin1, FrameOut o)
 {
-    int64_t n_pix = (int64_t)c.rows_local * c.W;
+    // grid = (row segments of EPILOGUE_BLOCK pixels, rows): no 64-bit division to find the row of a pixel
+    const int lrow = (int)blockIdx.y, ix = (int)(blockIdx.x * EPILOGUE_BLOCK + threadIdx.x);
+    const int64_t p = (int64_t)lrow * c.W + ix;
     StatAcc acc;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pix; p += (int64_t)gridDim.x * 256) {
-        int lrow = (int)(p / c.W), ix = (int)(p - (int64_t)lrow * c.W);
+    if (ix < c.W) {
         int src_row = lrow;
         if (c.use_tb && lrow >= c.H - c.H / 2) src_row = c.H - 1 - lrow; // quirk Q1 (image_lens.py:272-276)
         RayResult res;
@@ -813,7 +870,7 @@ __global__ void __launch_bounds__(256, 3) k_epilogue_frame(CamConsts c, MetricCo
         if (o.rgb || o.rgba) {
             float rgb[3]; int nch;
             int grow = local_to_global_row(c, lrow);
-            shade(c, o, ix, grow, fa32, (int)wl, rgb, nch);
+            shade<HAS_BG>(c, o, ix, grow, fa32, (int)wl, rgb, nch);
             if (o.rgb) for (int ch = 0; ch < nch; ++ch) o.rgb[p * nch + ch] = rgb[ch];
             if (o.rgba) { // matplotlib imsave: (x * 255).astype(uint8) in float32, alpha 255
                 uchar4 px;
@@ -825,7 +882,7 @@ __global__ void __launch_bounds__(256, 3) k_epilogue_frame(CamConsts c, MetricCo
             }
         }
     }
-    flush_stats(o.stats, acc);
+    flush_stats(o.stats, acc, m);
 }
 
 // ---- K3 with the background tile staged in LDS (north-star: "LDS staging of the background-image tile") ----
@@ -854,7 +911,9 @@ __global__ void __launch_bounds__(256, 3) k_epilogue_frame_lds(CamConsts c, Metr
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     StatAcc acc;
     unsigned long long staged = 0, fallback = 0; // tiles served from LDS / by the global gather (thread 0)
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    { // one 16x16 tile per workgroup (no loop: a loop around this body costs the kernel its registers, see k_epilogue_frame)
+        const int t = (int)blockIdx.x;
+        if (t >= n_tiles) return; // (block-uniform)
         const int tY = t / tiles_x, tX = t - tY * tiles_x;
         const int ix = tX * 16 + lx, lrow = tY * 16 + ly;
         const bool active = ix < c.W && lrow < c.rows_local;
@@ -921,13 +980,13 @@ __global__ void __launch_bounds__(256, 3) k_epilogue_frame_lds(CamConsts c, Metr
                 reinterpret_cast<uchar4 *>(o.rgba)[p] = px;
             }
         }
-        __syncthreads(); // bb and tile are rewritten by the next iteration
     }
-    if (o.stats && threadIdx.x == 0 && (staged | fallback)) {
-        atomicAdd((unsigned long long *)&o.stats[10], staged);
-        atomicAdd((unsigned long long *)&o.stats[11], fallback);
+    if (o.stats && threadIdx.x == 0 && (staged | fallback)) { // words 6, 7 of the workgroup's partial set -> LT_STAT_BG_TILES_LDS / _GLOBAL
+        unsigned long long *set = (unsigned long long *)o.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 8;
+        if (staged) atomicAdd(&set[6], staged);
+        if (fallback) atomicAdd(&set[7], fallback);
     }
-    flush_stats(o.stats, acc);
+    flush_stats(o.stats, acc, m);
 }
 
 // Epilogue of the batch twins: float64 final_alpha, int64 winding (metrics.py:667-668, :678-679).
