@@ -81,6 +81,10 @@ def parse(argv=None):
                          "frame, no longest-ray chain, no per-rank projection (what the profiling scripts pass)")
     ap.add_argument("--no-production-path", action="store_true",
                     help="skip the second timed region (the same frame with the reference's production integrator, DP45 float64)")
+    ap.add_argument("--extras", default="pipelined,production,chain,e2e,projection",
+                    help="which of the extras to run (comma list; --no-extras = none): pipelined (the K frames again, 3 in flight), "
+                         "production (second timed region, DP45 float64), chain (longest ray alone), e2e (host-pointer frame), "
+                         "projection (each rank of 2 / 4 / 8 alone on this GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each CPU baseline leg")
     ap.add_argument("--background", action="store_true", help="image_lens workload: lens a synthetic background")
     ap.add_argument("--frames-in-flight", type=int, default=1,
@@ -668,7 +672,9 @@ def main(argv=None):
         if trec and (trec.get("build_id") or tr.get("build_id")) == bid:
             roof["traffic"] = trec["bytes_per_launch"]
             roof["traffic_source"] = trec.get("source")
-        roof["algorithmic_bytes_per_launch"] = int(k_waves / steps * 64 * 12 * (4 if prec == 32 else 8))
+        # 16 B read + 32 B written per ray record (three 4-vectors of the integrator's type), padded tiles included
+        # (direct schedule: waves x 64 records; the queue schedule's few persistent waves sweep the same records)
+        roof["algorithmic_bytes_per_launch"] = int(max(k_waves / steps * 64, slow_rays) * 12 * (4 if prec == 32 else 8))
         roof["other_kernels_ms"] = {"prologue": round(R["per_rank"][slow][0], 4), "epilogue": round(R["per_rank"][slow][2], 4)}
         return roof, workload, key
 
@@ -700,30 +706,32 @@ def main(argv=None):
         return res
 
     F = max(1, args.frames_in_flight)
-    extras = not args.no_extras
-    H = run_region(args.integrator, args.precision, args.steps, args.warmup, F, args.pipelined_extra if extras else 0)
+    extras = set() if args.no_extras else {x.strip() for x in args.extras.split(",") if x.strip()}
+    H = run_region(args.integrator, args.precision, args.steps, args.warmup, F, args.pipelined_extra if "pipelined" in extras else 0)
 
     # ---- the reference's production path (metrics.py:419-567 via :1128-1132: DP45, float64), same frame, same K and W.
     # It is what `python image_lens.py --a 0.9` integrates with and what the plugin surface defaults to (metrics.py of
     # the product: dp45_exact); the headline above is the fixed-step float32 integrator BASELINE.json's north star names.
     P = None
-    want_prod = (extras and not args.no_production_path and args.metric == "kerr" and args.integrator == "rk4"
+    want_prod = ("production" in extras and not args.no_production_path and args.metric == "kerr" and args.integrator == "rk4"
                  and not args.background and n_parts == world)
     if want_prod:
         P = run_region("dp45_exact", 64, args.steps, min(args.warmup, 3), 1, 0)
 
     # untimed extras (rank 0, one GPU): longest-ray chain, host-pointer end-to-end frame, per-rank projection
     chain = e2e = proj = None
-    if rank == 0 and world == 1 and n_parts == 1 and extras and args.metric == "kerr":
-        d_steps = torch.empty((size, size), dtype=torch.int32, device=dev)
-        o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
-        o1.stream = main_stream.cuda_stream
-        ltrace.render_dev(cam, met, o1, d_steps=d_steps.data_ptr())
-        torch.cuda.synchronize(dev)
-        chain = longest_chain(ltrace, cam, met, args, d_steps.cpu().numpy(), np)
-        del d_steps
-        if not args.background:
+    if rank == 0 and world == 1 and n_parts == 1 and args.metric == "kerr":
+        if "chain" in extras:
+            d_steps = torch.empty((size, size), dtype=torch.int32, device=dev)
+            o1 = ltrace.default_opts(integrator=args.integrator, precision=args.precision, schedule=args.schedule)
+            o1.stream = main_stream.cuda_stream
+            ltrace.render_dev(cam, met, o1, d_steps=d_steps.data_ptr())
+            torch.cuda.synchronize(dev)
+            chain = longest_chain(ltrace, cam, met, args, d_steps.cpu().numpy(), np)
+            del d_steps
+        if not args.background and "e2e" in extras:
             e2e = end_to_end(ltrace, cam, met, args, np)
+        if not args.background and "projection" in extras:
             try:
                 proj = {args.integrator: projected_ranks(args.integrator, args.precision)}
                 if P is not None:

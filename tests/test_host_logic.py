@@ -169,3 +169,13 @@ def test_ctypes_structs_have_the_sizes_the_c_compiler_gives(tmp_path):
             ctypes.sizeof(ltrace.DenseOpts), ltrace.Opts.stream.offset, ltrace.DenseOpts.max_points.offset,
             ltrace.DenseOpts.stream.offset]
     assert got == want
+
+
+def test_design_md_tables_are_generated_from_the_profiles():
+    """DESIGN.md's numeric tables are written by tools/design_tables.py from profiles/r03_bench_*.json: a figure that
+    was refreshed under profiles/ but not in the document (or edited by hand in the document) fails here."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "design_tables.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 run() {
     echo "== bench.py $*"
-    python3 bench.py --no-cpu-baseline --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 | python3 -c "
+    python3 bench.py --no-cpu-baseline --extras pipelined --steps 10 --warmup 3 "$@" 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.readline()); r = d['roofline']; c = d['config']
 print(f\"{d['value']:.1f} Mrays/s  {d['ms_per_step']:.4f} ms/frame  integrate {r['avg_launch_ms']:.4f} ms  prologue/epilogue {r['other_kernels_ms']['prologue']:.3f}/{r['other_kernels_ms']['epilogue']:.3f} ms  \"
