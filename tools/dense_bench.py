@@ -23,6 +23,26 @@ import ltrace  # noqa: E402
 import metrics  # noqa: E402
 
 F_RHS, F_ATTEMPT = 218, 544
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+PEAK_F64_ISSUE = 1024 * 2.4e9 / 4      # wave-instructions per second: 1024 SIMDs, one float64 VALU instruction per 4 cycles
+
+
+def roofline(key, ms_tracks):
+    """k_dense_tracks against the float64 VALU issue peak, from the SQ_INSTS_VALU count committed for this workload and
+    this build (profiles/valu_counts.json, written by tools/prof_dense.sh); None without a matching record."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_counts.json")) as f:
+            rec = (json.load(f).get("workloads") or {}).get(key)
+    except (OSError, ValueError):
+        rec = None
+    if not rec:
+        return None
+    fresh = rec.get("build_id") == ltrace.build_id()
+    ms = rec["kernel_ms_in_the_profiled_run"] if ms_tracks is None else ms_tracks
+    return {"bound": "valu_issue_fp64", "kernel": "k_dense_tracks", "valu_wave_insts_per_launch": rec["valu_insts"],
+            "lane_utilisation": rec.get("lane_utilisation"), "kernel_ms": round(ms, 3),
+            "frac": round(rec["valu_insts"] / (ms * 1e-3) / PEAK_F64_ISSUE, 4),
+            "source": rec.get("source", "") + ("" if fresh else f"; STALE: measured on build {rec.get('build_id')}")}
 
 
 def states(n, a, seed=3):
@@ -75,7 +95,12 @@ def main():
     pts_full = int(cnt.sum()); evals = int(nf.sum())
     attempts = (evals - 2 * n) / 6
     flops = evals * F_RHS + attempts * F_ATTEMPT
+    # the main kernel alone, by HIP events around a launch of its own (caller order: the launch is that kernel; binned: the
+    # predictor and the sort run first, so the record's own time from the traced run prices the kernel)
+    key = f"dense_tracks|kerr_a{a}|n{n}|mp{mp}|binning{binning}"
+    roof = roofline(key, ms if binning < 0 else None)
     print(json.dumps(dict(workload=f"dense tracks Kerr a={a} r_obs=50, n={n}, max_points={mp}", length_binning=binning, ms=round(ms, 3),
+                          **({"roofline": roof} if roof else {}),
                           tracks_per_s=round(n / ms * 1e3), points_per_s=round(pts / ms * 1e3),
                           points_per_track=round(pts_full / n, 1), truncated=int((cnt > mp).sum()),
                           rhs_evals_per_track=round(evals / n, 1), rejected_frac=round(1 - (pts_full - n) / attempts, 4),

@@ -77,6 +77,14 @@ for k, v in d.get('projected_ranks', {}).items():
       echo "## memory-pipe counters of k_dense_tracks, caller order against length-binned (tools/pmc_dense.sh)"; cat $G/pmc_dense/summary.txt
       echo "## throughput by batch size: length_binning -1 (caller order) and 0 (automatic)"; cat $G/dense_bench.log
       grep -v amdgpu $G/dense_lane_stats.log; cat $G/dense_oracle.log; } > $P/${R}_dense_tracks.txt
+    python3 - <<'PY'
+import glob, json
+p = "profiles/valu_counts.json"
+d = json.load(open(p))
+for f in glob.glob("gpurun_out/prof_dense_*/valu_record.json"):
+    d["workloads"].update(json.load(open(f)))
+json.dump(d, open(p, "w"), indent=1)
+PY
     ls -la $P | grep $R
 else
     echo "usage: $0 measure [quick]|collect"; exit 2
