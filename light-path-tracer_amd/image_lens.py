@@ -18,6 +18,7 @@ float64 operations and stay on the host.  No CPU tracer exists in this package.
 """
 from time import perf_counter
 
+import json
 import os
 
 import numpy as np
@@ -123,21 +124,32 @@ def _empty_lookup(shape):
     return np.full(shape, np.nan, dtype=np.float32), np.zeros(shape, dtype=WINDING_DTYPE)
 
 
-def precompute_final_alpha_lookup(alpha_lookup, alpha_crit, r_obs, metric):
+def precompute_final_alpha_lookup(alpha_lookup, alpha_crit, r_obs, metric, dedup=False):
     """Spherically symmetric metrics: every pixel traced from its alpha alone.
-    -> (final_alpha f32, winding u16, total_rays, traced_rays)."""
+    -> (final_alpha f32, winding u16, total_rays, traced_rays).
+
+    dedup=True traces every DISTINCT float32 alpha once and hands the result to all pixels that share it (the idea of
+    the reference's dormant debugging_image_lense.py:634): a pinhole frame has 8-fold symmetry, so at most
+    ~N/8 + O(sqrt N) values are distinct.  Same alpha, same ray: the lookups are byte-identical to the full trace; only
+    `traced_rays` differs.  Off by default, as in the reference's live function (which traces all N)."""
     alpha = alpha_lookup.ravel().astype(np.float64)
     n = alpha.size
     if n == 0:
         fa, w = _empty_lookup(alpha_lookup.shape)
         return fa, w, n, 0
-    fa = np.full(n, np.nan, dtype=np.float64)
-    w = np.zeros(n, dtype=np.int64)
-    for lo in range(0, n, TRACE_CHUNK):
-        hi = min(lo + TRACE_CHUNK, n)
+    inverse = None
+    if dedup:
+        alpha, inverse = np.unique(alpha, return_inverse=True)
+    m = alpha.size
+    fa = np.full(m, np.nan, dtype=np.float64)
+    w = np.zeros(m, dtype=np.int64)
+    for lo in range(0, m, TRACE_CHUNK):
+        hi = min(lo + TRACE_CHUNK, m)
         metric.trace_rays_batch(r_obs, alpha[lo:hi], fa[lo:hi], w[lo:hi])
+    if inverse is not None:
+        fa, w = fa[inverse.ravel()], w[inverse.ravel()]
     return (fa.astype(np.float32).reshape(alpha_lookup.shape),
-            np.clip(w, 0, WINDING_MAX).astype(WINDING_DTYPE).reshape(alpha_lookup.shape), n, n)
+            np.clip(w, 0, WINDING_MAX).astype(WINDING_DTYPE).reshape(alpha_lookup.shape), n, m)
 
 
 def precompute_final_alpha_lookup_2d(alpha_lookup, fov, alpha_crit, r_obs, metric,
@@ -284,9 +296,39 @@ def write_png_rgba8(path, rgba, level=1):
         f.write(chunk(b"IEND", b""))
 
 
+def _lookup_cache_key(metric, r_obs, shape, fov, psi, mirror):
+    """Everything the lookups depend on: metric and its backend knobs, observer, camera, the mirror quirk, and the build
+    of the library that traced them (a new kernel build never reuses an old cache)."""
+    return json.dumps({"metric": type(metric).__name__, "M": float(metric.M), "a": float(getattr(metric, "a", 0.0)),
+                       "integrator": getattr(metric, "integrator", None), "precision": int(getattr(metric, "precision", 64)),
+                       "r_obs": float(r_obs), "shape": [int(shape[0]), int(shape[1])], "fov": [float(fov[0]), float(fov[1])],
+                       "psi": [float(psi[0]), float(psi[1])], "mirror": bool(mirror), "build": ltrace.build_id()}, sort_keys=True)
+
+
+def load_lookup_cache(path, key):
+    """(final_alpha, winding) from `path` if it was written for `key`, else None.  The file is ours (np.savez of two arrays
+    and a JSON string): loaded without pickle."""
+    try:
+        with np.load(path, allow_pickle=False) as z:
+            if str(z["key"]) == key:
+                return z["final_alpha"].copy(), z["winding"].copy()
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
+def save_lookup_cache(path, key, final_alpha, winding):
+    np.savez(path, key=np.array(key), final_alpha=final_alpha, winding=winding)
+
+
 def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_fov_deg=40.0,
          image_path="image.jpg", output_path="lensed_image.png", synthetic=None, staged=False,
-         integrator=None, precision=None, schedule=None, gpus=1, full_trace=False):
+         integrator=None, precision=None, schedule=None, gpus=1, full_trace=False, dedup_alpha=False,
+         lookup_cache=None):
+    """`lookup_cache`: path of an .npz (the reference's .gitignore names `lookup_cache.npz`, it never wrote one): the
+    final_alpha / winding lookups of this metric, observer and camera are stored there and reused by the next call with
+    the same settings -- a new background then costs one colouring pass (lt_shade) instead of a trace.
+    `dedup_alpha`: staged path, spherically symmetric metrics: trace distinct alphas only (precompute_final_alpha_lookup)."""
     import matplotlib.image as mpimg
 
     if metric is None:
@@ -321,31 +363,47 @@ def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_f
     print(f"BH screen offset: psi_y={np.degrees(psi[0]):.4f} deg, psi_x={np.degrees(psi[1]):.4f} deg ({where})")
 
     rgba8 = None
-    if staged:
+    mirror = (not full_trace) and gpus <= 1 and not metric.is_spherically_symmetric and abs(psi[0]) <= 1e-8
+    # (the staged path mirrors whenever the reference does, the fused one unless --full-trace / several GPUs)
+    mirrored = (not metric.is_spherically_symmetric and abs(psi[0]) <= 1e-8) if staged else mirror
+    cache_key = _lookup_cache_key(metric, r_obs, (height, width), fov, psi, mirrored) if lookup_cache else None
+    cached = load_lookup_cache(lookup_cache, cache_key) if lookup_cache else None
+    if cached is not None:
+        print(f"Lookup cache hit ({lookup_cache}): colouring only")
+        fa, wd = cached
+        t0 = perf_counter()
+        lensed = render_lensed_image(img, None, fa, wd, alpha_crit, fov, False, psi=psi)
+        timings["render"] = perf_counter() - t0
+        total, traced = height * width, 0
+    elif staged:
         print("Building per-pixel " + ("alpha" if metric.is_spherically_symmetric else "(alpha, theta)") + " lookup...")
         t0 = perf_counter()
         alpha_lookup = build_alpha_lookup((height, width), fov, psi=psi)
         timings["build_lookup"] = perf_counter() - t0
         t0 = perf_counter()
         if metric.is_spherically_symmetric:
-            fa, wd, total, traced = precompute_final_alpha_lookup(alpha_lookup, alpha_crit, r_obs, metric)
+            fa, wd, total, traced = precompute_final_alpha_lookup(alpha_lookup, alpha_crit, r_obs, metric, dedup=dedup_alpha)
         else:
             fa, wd, total, traced = precompute_final_alpha_lookup_2d(alpha_lookup, fov, alpha_crit, r_obs, metric, psi=psi)
         timings["precompute"] = perf_counter() - t0
         t0 = perf_counter()
         lensed = render_lensed_image(img, alpha_lookup, fa, wd, alpha_crit, fov, False, psi=psi)
         timings["render"] = perf_counter() - t0
+        if lookup_cache:
+            save_lookup_cache(lookup_cache, cache_key, fa, wd)
     else:
         # The reference traces the top half of the frame and mirrors it whenever the observer is equatorial and the
         # hole is not offset vertically (image_lens.py:218-220, :272-276 -- off by one row, quirk Q1).  Default: do
         # as the reference does, so that `python image_lens.py --a 0.9` gives the reference's picture; --full-trace
         # (and every multi-GPU render) traces every row instead.
-        mirror = (not full_trace) and gpus <= 1 and not metric.is_spherically_symmetric and abs(psi[0]) <= 1e-8
         print(f"Fused GPU render (pixel -> ray -> colour) on {max(gpus, 1)} GPU(s); rows: "
               + ("top half traced, bottom half mirrored as in the reference" if mirror else "every row traced"))
         t0 = perf_counter()
-        out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=mirror, want=("rgb", "rgba"), gpus=gpus)
+        out = render_frame(img, metric, r_obs, fov, psi=psi, tb_symmetry=mirror,
+                           want=("rgb", "rgba") + (("fa", "winding") if lookup_cache else ()), gpus=gpus)
         timings["render"] = perf_counter() - t0
+        if lookup_cache:
+            save_lookup_cache(lookup_cache, cache_key, np.asarray(out["fa"]), np.asarray(out["winding"]))
         timings["gpu_integrate_ms"] = out["stats"]["integrate_ms"]
         lensed, total, traced = out["rgb"], height * width, out["stats"]["rays"]   # mirrored rows are copies, not rays
         rgba8 = out["rgba"] if lensed.ndim == 3 else None
@@ -370,6 +428,9 @@ if __name__ == "__main__":
     ap.add_argument("--psi-y", type=float, default=0.0, help="BH vertical offset in deg (+ = top, - = bottom)")
     ap.add_argument("--psi-x", type=float, default=0.0, help="BH horizontal offset in deg (+ = right, - = left)")
     ap.add_argument("--fov-v", type=float, default=40.0, help="Vertical field of view in deg")
+    ap.add_argument("--lookup-cache", default=None, help="path of an .npz holding the final_alpha / winding lookups: written after a "
+                                                         "trace, reused by the next call with the same metric, observer and camera")
+    ap.add_argument("--dedup-alpha", action="store_true", help="--staged, a = 0: trace every distinct alpha once")
     # backend additions
     ap.add_argument("--image", default="image.jpg", help="background image (default: image.jpg)")
     ap.add_argument("--output", default="lensed_image.png")
@@ -385,4 +446,4 @@ if __name__ == "__main__":
     main(M=args.M, a=args.a, r_obs_mult=args.r_obs, psi=(np.radians(args.psi_y), np.radians(args.psi_x)),
          vertical_fov_deg=args.fov_v, image_path=args.image, output_path=args.output, synthetic=args.synthetic,
          staged=args.staged, integrator=args.integrator, precision=args.precision, schedule=args.schedule,
-         gpus=args.gpus, full_trace=args.full_trace)
+         gpus=args.gpus, full_trace=args.full_trace, dedup_alpha=args.dedup_alpha, lookup_cache=args.lookup_cache)

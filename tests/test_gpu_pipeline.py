@@ -136,6 +136,29 @@ def test_drop_in_defaults_are_the_reference_arithmetic(tmp_path):
     assert 1e-9 < np.nanmax(np.abs(fast["fa"] - g["final_alpha"])) <= 2e-4
 
 
+def test_alpha_dedup_and_lookup_cache(tmp_path, capsys):
+    """tracing every distinct alpha once gives byte-identical Schwarzschild lookups; a lookup cache written by
+    one call is reused by the next call with the same metric, observer and camera (and by no other)."""
+    g, m = _g("48x64_a0")
+    S = metrics.Schwarzschild()
+    full = image_lens.precompute_final_alpha_lookup(g["alpha_lookup"], m["alpha_crit"], m["r_obs"], S)
+    dd = image_lens.precompute_final_alpha_lookup(g["alpha_lookup"], m["alpha_crit"], m["r_obs"], S, dedup=True)
+    assert np.array_equal(full[0], dd[0], equal_nan=True) and np.array_equal(full[1], dd[1])
+    assert full[2] == dd[2] == 48 * 64 and full[3] == 48 * 64 and dd[3] == np.unique(g["alpha_lookup"]).size < 48 * 64 / 3
+    cache = str(tmp_path / "lookup_cache.npz")
+    kw = dict(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), lookup_cache=cache)
+    first = image_lens.main(output_path=str(tmp_path / "a.png"), **kw)
+    assert "cache hit" not in capsys.readouterr().out and os.path.exists(cache)
+    second = image_lens.main(output_path=str(tmp_path / "b.png"), **kw)
+    assert "Lookup cache hit" in capsys.readouterr().out
+    np.testing.assert_array_equal(first, second)
+    other = image_lens.main(output_path=str(tmp_path / "c.png"), **dict(kw, a=0.5))     # another metric: a miss, then rewritten
+    assert "cache hit" not in capsys.readouterr().out and not np.array_equal(other, first)
+    staged = image_lens.main(output_path=str(tmp_path / "d.png"), staged=True, dedup_alpha=True, a=0.0, r_obs_mult=100.0, synthetic=(96, 64))
+    plain = image_lens.main(output_path=str(tmp_path / "e.png"), staged=True, a=0.0, r_obs_mult=100.0, synthetic=(96, 64))
+    np.testing.assert_array_equal(staged, plain)
+
+
 def test_cli_main_runs_end_to_end(tmp_path, capsys):
     out = tmp_path / "lensed.png"
     img = image_lens.main(a=0.9, r_obs_mult=100.0, synthetic=(96, 64), output_path=str(out))
