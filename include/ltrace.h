@@ -284,6 +284,9 @@ void lt_default_dense_opts(lt_dense_opts *o);
 /* HOST pointers.  state0 (n, 8).  Records are track-major, the reference's solution.t / solution.y per track:
  *   out_t (n, max_points), out_y (n, max_points, 8): track i's k-th point is out_t[i*max_points + k],
  *   out_y[(i*max_points + k)*8 + c] -- solution.t[k], solution.y[c, k].  (Version 100 wrote them point-major.)
+ *   A track that ended on a radius event and whose record has room holds ONE more value, out_t[i*max_points + count]:
+ *   the affine parameter at which the step containing the event would have ended (solve_ivp's `solution.sol` interpolates
+ *   the last stretch with the dense output of that whole step; geodesic_tracer.Track.sol rebuilds it from this).
  *   out_count (n): points of the complete record.  If it exceeds max_points only the first
  *   max_points - 1 points are kept and the last slot holds the final point.
  *   out_status (n): LT_TRACK_*.   out_nfev (n): right-hand-side evaluations (solution.nfev). */

@@ -384,6 +384,11 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
         }
         push(te, ye);
         status = take_in ? 1 : 2;
+        // One value past the record: where the step that holds the event would have ended.  solve_ivp's continuous solution
+        // (`solution.sol`) interpolates the last stretch with the dense output of that WHOLE step; with this the host can
+        // rebuild it (geodesic_tracer.Track.sol).  The slot is outside the track's `count` points and only written when
+        // the record has room.
+        if (n_pts < k.max_points) o.t[rec0 + n_pts] = t_new;
     }
     flush_t((n_pts < k.max_points - 1 ? n_pts : (int32_t)k.max_points - 1) - nt);
     o.count[i] = n_pts;

@@ -53,16 +53,68 @@ def trace_ray(metric, r_obs, alpha, **kwargs):
 class Track:
     """One trajectory of a GPU batch, with the fields the reference's callers read off solve_ivp's result:
     t (n_points,), y (8, n_points) = rows t, r, theta, phi, p_t, p_r, p_theta, p_phi; status as solve_ivp
-    (1 a radius event ended it, 0 lambda_max reached, -1 failed), nfev, success.  `event` names the
-    event ('captured' / 'escaped' / None); `truncated` says the record did not fit `max_points` (then
-    the last point is still the final one)."""
-    __slots__ = ("t", "y", "status", "nfev", "event", "truncated", "success")
+    (1 a radius event ended it, 0 lambda_max reached, -1 failed), nfev, success, and `sol(t)`, the continuous
+    solution.  `event` names the event ('captured' / 'escaped' / None); `truncated` says the record did not fit
+    `max_points` (then the last point is still the final one, and there is no dense output)."""
+    __slots__ = ("t", "y", "status", "nfev", "event", "truncated", "success", "_metric", "_t_step_end", "_segments")
 
-    def __init__(self, t, y, code, nfev, truncated):
+    def __init__(self, t, y, code, nfev, truncated, metric=None, t_step_end=None):
         self.t, self.y, self.nfev, self.truncated = t, y, int(nfev), bool(truncated)
         self.status = 1 if code in (ltrace.TRACK_CAPTURE_EVENT, ltrace.TRACK_ESCAPE_EVENT) else (0 if code == 0 else -1)
         self.event = {ltrace.TRACK_CAPTURE_EVENT: "captured", ltrace.TRACK_ESCAPE_EVENT: "escaped"}.get(code)
         self.success = self.status >= 0
+        self._metric, self._t_step_end, self._segments = metric, t_step_end, {}
+
+    # Dormand-Prince 5(4) tableau and Shampine's dense-output matrix (what scipy's RK45 uses)
+    _C = np.array([0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1])
+    _A = [[], [1 / 5], [3 / 40, 9 / 40], [44 / 45, -56 / 15, 32 / 9], [19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729],
+          [9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656]]
+    _B = np.array([35 / 384, 0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84])
+    _P = np.array([[1, -8048581381 / 2820520608, 8663915743 / 2820520608, -12715105075 / 11282082432], [0, 0, 0, 0],
+                   [0, 131558114200 / 32700410799, -68118460800 / 10900136933, 87487479700 / 32700410799],
+                   [0, -1754552775 / 470086768, 14199869525 / 1410260304, -10690763975 / 1880347072],
+                   [0, 127303824393 / 49829197408, -318862633887 / 49829197408, 701980252875 / 199316789632],
+                   [0, -282668133 / 205662961, 2019193451 / 616988883, -1453857185 / 822651844],
+                   [0, 40617522 / 29380423, -110615467 / 29380423, 69997945 / 29380423]])
+
+    def _segment(self, k):
+        """(t_old, h, y_old, Q) of the step that starts at point k: the step's stages formed again on the host from the
+        metric's own 8-D equations -- the same dense output solve_ivp keeps per step (RkDenseOutput)."""
+        seg = self._segments.get(k)
+        if seg is None:
+            last = k == len(self.t) - 2
+            t_end = self._t_step_end if (last and self.status == 1 and self._t_step_end is not None) else self.t[k + 1]
+            t0, h, y0 = self.t[k], t_end - self.t[k], self.y[:, k]
+            f = self._metric.geodesic_equations
+            K = np.empty((7, 8))
+            K[0] = f(t0, y0)
+            for s_ in range(1, 6):
+                K[s_] = f(t0 + self._C[s_] * h, y0 + h * (np.array(self._A[s_]) @ K[:s_]))
+            K[6] = f(t0 + h, y0 + h * (self._B @ K[:6]))
+            seg = self._segments[k] = (t0, h, y0, K.T @ self._P)
+        return seg
+
+    def sol(self, t):
+        """The track as a function of the affine parameter, like `solution.sol` of the reference's
+        `solve_ivp(..., dense_output=True)` (geodesic_tracer.py:57-67): -> (8,) for a scalar t, (8, n) for an array, valid
+        on [t[0], t[-1]].  Each step's 4th-order dense output is rebuilt on the host from the stored points (7 evaluations
+        of metric.geodesic_equations per step touched, cached); nothing in the reference calls it -- it is here so that the
+        object a caller gets back has the surface solve_ivp's has."""
+        if self._metric is None:
+            raise RuntimeError("this Track was built without its metric: no dense output")
+        if self.truncated:
+            raise RuntimeError("the record was truncated (max_points): steps are missing, no dense output")
+        ts = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        if len(self.t) < 2:
+            out = np.repeat(self.y[:, :1], ts.size, axis=1)
+        else:
+            seg = np.clip(np.searchsorted(self.t, ts, side="right") - 1, 0, len(self.t) - 2)
+            out = np.empty((8, ts.size))
+            for j, (k, tj) in enumerate(zip(seg, ts)):
+                t0, h, y0, Q = self._segment(int(k))
+                x = (tj - t0) / h
+                out[:, j] = y0 + h * (Q @ (x ** np.arange(1, 5)))
+        return out[:, 0] if np.ndim(t) == 0 else out
 
 
 def _lt_metric(metric):
@@ -90,7 +142,9 @@ def integrate_geodesics(metric, states0, lambda_max=1000.0, r_stop_inner=None, r
     out = []
     for i in range(s0.shape[0]):
         m = min(int(count[i]), int(max_points))
-        trk = Track(t[i, :m].copy(), np.ascontiguousarray(y[i, :m].T), int(status[i]), nfev[i], count[i] > max_points)
+        step_end = float(t[i, m]) if (status[i] > 0 and count[i] < max_points) else None   # one value past the record: see lt_integrate_dense
+        trk = Track(t[i, :m].copy(), np.ascontiguousarray(y[i, :m].T), int(status[i]), nfev[i], count[i] > max_points,
+                    metric=metric, t_step_end=step_end)
         out.append((trk, "captured" if trk.y[1, -1] <= 1.1 * r_in else "escaped"))
     return out
 

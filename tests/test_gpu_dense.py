@@ -219,6 +219,28 @@ def test_host_mirror_trace_rays_matches_scipy_path():
             assert np.max(np.abs(trk.y - sol.y) / (1 + np.abs(sol.y))) < 1e-8
 
 
+def test_track_sol_is_solve_ivps_dense_output():
+    """Track.sol(t) against `solution.sol(t)` of the scipy path (the reference asks solve_ivp for dense_output=True,
+    geodesic_tracer.py:66): interior steps and the last stretch before the terminal event, which solve_ivp interpolates
+    with the dense output of the whole step that contains the event."""
+    rng = np.random.default_rng(4)
+    for met in (metrics.Schwarzschild(1.0), metrics.Kerr(1.0, 0.9)):
+        degs = [2, 5.97, 8, 15]
+        fan = gt.trace_rays(met, 50.0, np.radians(degs))
+        for deg, (trk, outcome) in zip(degs, fan):
+            sol, oc = gt.trace_ray(met, 50.0, np.radians(deg))
+            ts = np.concatenate([rng.uniform(sol.t[0], sol.t[-1], 40), sol.t[-1] - np.array([0.0, 1e-3, 0.3]) * (sol.t[-1] - sol.t[-2]),
+                                 sol.t[[0, 1, 5]]])
+            got, exp = trk.sol(ts), sol.sol(ts)
+            assert got.shape == exp.shape == (8, ts.size)
+            assert np.max(np.abs(got - exp) / (1 + np.abs(exp))) < 1e-8, deg
+            assert np.allclose(trk.sol(float(sol.t[3])), sol.y[:, 3], rtol=0, atol=1e-8)
+    cut = gt.integrate_geodesics(met, [met.initial_conditions(50.0, 0.2)], max_points=16)[0][0]
+    assert cut.truncated
+    with pytest.raises(RuntimeError):
+        cut.sol(1.0)
+
+
 def test_dense_error_codes():
     lm = _metric(1.0, 0.0, False)
     s0 = np.zeros((1, 8))
