@@ -701,6 +701,8 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
     c.trace_rows = c.use_tb ? (c.H + 1) / 2 : c.rows_local;
     c.tiles_x = (c.W + 7) / 8;
     if (c.rows_local <= 0) return LT_OK; // a partition may own no rows
+    if (c.rows_local > 65535) // (the epilogue's launch grid carries the row in its y dimension; checked before anything is launched)
+        return fail(LT_ERR_UNSUPPORTED, "a partition of %d rows exceeds the epilogue's launch grid (65535 rows): split it (n_parts)", c.rows_local);
     int tiles_y = (c.trace_rows + 7) / 8;
     c.tiles_y = tiles_y;
     { // "hot" tile rectangle, queued first: bounds the critical curve (largest impact parameter of a
@@ -788,7 +790,6 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
         else k_epilogue_frame_lds<double><<<gp, 256, 0, s>>>(c, mc, (const double4 *)fin0, (const double4 *)fin1, fo);
     } else {
         const bool has_bg = d_bg != nullptr && (d_rgb || d_rgba);
-        if (c.rows_local > 65535) return fail(LT_ERR_UNSUPPORTED, "a partition of %d rows exceeds the launch grid (65535 rows)", c.rows_local);
         const dim3 ge((unsigned)((c.W + EPILOGUE_BLOCK - 1) / EPILOGUE_BLOCK), (unsigned)c.rows_local);
         if (o.precision == 32) {
             if (has_bg) k_epilogue_frame<float, true><<<ge, EPILOGUE_BLOCK, 0, s>>>(c, mc, (const float4 *)fin0, (const float4 *)fin1, fo);

@@ -30,6 +30,12 @@ struct DenseConsts {
     int32_t max_attempts; // guard: a track that needs more step attempts ends with status -2 (solve_ivp has no such limit)
 };
 
+// p_t (component 4) and p_phi (component 7) are cyclic: their derivatives are identically zero, so a stage sum leaves them
+// unchanged and their error estimate is exactly 0 -- in solve_ivp's arithmetic too (y + h * 0, 0 / scale).  Written out
+// per component the compiler cannot drop that work without fast-math (0 * h is not 0 for a non-finite h), which was 1/4 of
+// the stage sums and error scales; the integrators below skip the two components by hand.  Bit-identical.
+__device__ __forceinline__ constexpr bool dense_cyclic(int c) { return c == 4 || c == 7; }
+
 // 8-D Hamilton equations of H = g^{mu nu} p_mu p_nu / 2 in Boyer-Lindquist coordinates, state
 // (t, r, theta, phi, p_t, p_r, p_theta, p_phi).  Same separable form as the 5-D one of lt_device.hpp
 // (2 Sigma H = Delta p_r^2 + p_theta^2 + D^2 / sin^2 - P^2 / Delta, D = L - a E sin^2, P = E (r^2 + a^2) - a L)
@@ -281,23 +287,23 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
     auto stages = [&](double hh, double *yn, double *k3, double *k4, double *k5, double *k6, double *k7) {
         double k2[8], tmp[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * hh;
+        for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A21) * hh;
         rhs8_near(k, tmp, y[2], s0, c0, k2, ss, cc);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * hh;
+        for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A31 + k2[c] * A32) * hh;
         rhs8_near(k, tmp, y[2], s0, c0, k3, ss, cc);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * hh;
+        for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * hh;
         rhs8_near(k, tmp, y[2], s0, c0, k4, ss, cc);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * hh;
+        for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * hh;
         rhs8_near(k, tmp, y[2], s0, c0, k5, ss, cc);
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * hh;
+            tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * hh;
         rhs8_near(k, tmp, y[2], s0, c0, k6, ss, cc);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) yn[c] = y[c] + hh * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
+        for (int c = 0; c < 8; ++c) yn[c] = dense_cyclic(c) ? y[c] : y[c] + hh * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
         rhs8_near(k, yn, y[2], s0, c0, k7, sn, cn);
     };
     double h = 0, t_new = 0;
@@ -321,6 +327,7 @@ __global__ void __launch_bounds__(64, LT_DENSE_WAVES) k_dense_tracks(DenseConsts
         double e[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+            if (dense_cyclic(c)) { e[c] = 0.0; continue; }
             double ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * h;
             e[c] = ec * M<double>::rcp_pos(k.atol + fmax(fabs(y[c]), fabs(yn[c])) * k.rtol); // (>= atol > 0)
         }
@@ -524,26 +531,27 @@ __global__ void __launch_bounds__(64) k_dense_predict(PredictConsts<T> k, const 
                 T hh = M<T>::min(h, k.lambda_max - t);
                 T k2[8], k3[8], k4[8], k5[8], k6[8], k7[8], tmp[8], yn[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A21) * hh;
+                for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A21) * hh;
                 rhs8_t(k, tmp, k2);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A31 + k2[c] * A32) * hh;
+                for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A31 + k2[c] * A32) * hh;
                 rhs8_t(k, tmp, k3);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * hh;
+                for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A41 + k2[c] * A42 + k3[c] * A43) * hh;
                 rhs8_t(k, tmp, k4);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * hh;
+                for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A51 + k2[c] * A52 + k3[c] * A53 + k4[c] * A54) * hh;
                 rhs8_t(k, tmp, k5);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) tmp[c] = y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * hh;
+                for (int c = 0; c < 8; ++c) tmp[c] = dense_cyclic(c) ? y[c] : y[c] + (f[c] * A61 + k2[c] * A62 + k3[c] * A63 + k4[c] * A64 + k5[c] * A65) * hh;
                 rhs8_t(k, tmp, k6);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) yn[c] = y[c] + hh * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
+                for (int c = 0; c < 8; ++c) yn[c] = dense_cyclic(c) ? y[c] : y[c] + hh * (f[c] * B1 + k3[c] * B3 + k4[c] * B4 + k5[c] * B5 + k6[c] * B6);
                 rhs8_t(k, yn, k7);
                 T e[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
+                    if (dense_cyclic(c)) { e[c] = T(0); continue; }
                     T ec = (f[c] * E1 + k3[c] * E3 + k4[c] * E4 + k5[c] * E5 + k6[c] * E6 + k7[c] * E7) * hh;
                     e[c] = ec * M<T>::rcp(k.atol + M<T>::max(M<T>::abs(y[c]), M<T>::abs(yn[c])) * k.rtol);
                 }

@@ -8,6 +8,8 @@ Partition: block-cyclic rows -- block b of `row_block` rows belongs to rank b % 
 far from uniform (shadow rows are cheap, critical-curve rows expensive), so contiguous slabs would
 leave most GPUs idle; small cyclic blocks give every rank the same mix.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -73,7 +75,6 @@ class FrameGather:
     largest) -- a diagnostic switch for a transport that mishandles grouped send/recv, not a second product path."""
 
     def __init__(self, height, width, channels, dtype, device, row_block, world=None, rank=None, owner=None):
-        import os
         self.world = dist.get_world_size() if world is None else world
         self.rank = dist.get_rank() if rank is None else rank
         self.h, self.w, self.c = height, width, channels
