@@ -14,6 +14,41 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, "profiles")
 BEGIN, END = "<!-- BEGIN GENERATED: tools/design_tables.py -->", "<!-- END GENERATED -->"
+BEGIN2, END2 = "<!-- BEGIN GENERATED frames-in-flight: tools/design_tables.py -->", "<!-- END GENERATED frames-in-flight -->"
+
+
+def flight_block():
+    """The frames-in-flight table of section 5.2 from profiles/r03_frames_in_flight.txt (tools/pipeline_bench.sh)."""
+    rows = {}
+    with open(os.path.join(PROF, "r03_frames_in_flight.txt")) as f:
+        for line in f:
+            m = re.match(r"(--size .*?--frames-in-flight (\d))\s+([\d.]+) Mrays/s\s+([\d.]+) ms/frame.*region ([\d.]+|None)", line)
+            if m:
+                key = re.sub(r"\s*--frames-in-flight \d", "", m.group(1)).strip()
+                rows.setdefault(key, {})[int(m.group(2))] = (float(m.group(3)), float(m.group(4)), m.group(5))
+    names = {"--size 4096": ("4096² whole frame", "rate"), "--size 2048": ("2048² whole frame (config 3)", "rate"),
+             "--size 4096 --emulate-parts 2 --emulate-part 1": ("one rank of 2 (4096²)", "ms"),
+             "--size 4096 --emulate-parts 4 --emulate-part 1": ("one rank of 4", "ms"),
+             "--size 4096 --emulate-parts 8 --emulate-part 1": ("one rank of 8", "ms"),
+             "--size 4096 --integrator dp45 --precision 64": ("4096² DP45 float64", "rate")}
+    out = [BEGIN2, "", "| workload | F = 1 | F = 2 | F = 3 | chip-level issue fraction of the region, F = 1 → best |", "|---|---|---|---|---|"]
+    for key, (label, kind) in names.items():
+        r = rows.get(key)
+        if not r:
+            continue
+        def cell(F):
+            if F not in r:
+                return "—"
+            v, ms, _ = r[F]
+            return f"{v:.0f} Mrays/s ({ms:.2f} ms)" if kind == "rate" else f"{ms:.2f} ms"
+        regs = [float(r[F][2]) for F in sorted(r) if r[F][2] != "None"]
+        out.append(f"| {label} | {cell(1)} | {cell(2)} | {cell(3)} | " + (f"{regs[0]:.2f} → {max(regs):.2f}" if regs else "—") + " |")
+    r8 = rows.get("--size 4096 --emulate-parts 8 --emulate-part 1", {})
+    if 1 in r8 and 3 in r8:
+        out += ["", f"(one rank of 8 with three frames in flight renders its share of a frame every {r8[3][1]:.2f} ms: 8 ranks ≈ "
+                    f"{4096 * 4096 / r8[3][1] / 1e3:.0f} Mrays/s before the gather, against ≈ {4096 * 4096 / r8[1][1] / 1e3:.0f} one frame at a time)"]
+    out += ["", END2]
+    return "\n".join(out)
 
 
 def load(name):
@@ -89,18 +124,23 @@ def main():
     new = block()
     if "--print" in sys.argv:
         print(new)
+        print(flight_block())
         return 0
-    m = re.search(re.escape(BEGIN) + r".*?" + re.escape(END), doc, re.S)
-    if not m:
-        print("DESIGN.md has no GENERATED block", file=sys.stderr)
-        return 1
+    stale = False
+    for begin, end, text in ((BEGIN, END, new), (BEGIN2, END2, flight_block())):
+        m = re.search(re.escape(begin) + r".*?" + re.escape(end), doc, re.S)
+        if not m:
+            print(f"DESIGN.md has no block {begin}", file=sys.stderr)
+            return 1
+        stale = stale or m.group(0) != text
+        doc = doc[:m.start()] + text + doc[m.end():]
     if "--check" in sys.argv:
-        if m.group(0) != new:
-            print("DESIGN.md's generated block is stale: run python tools/design_tables.py", file=sys.stderr)
+        if stale:
+            print("DESIGN.md's generated blocks are stale: run python tools/design_tables.py", file=sys.stderr)
             return 1
         return 0
     with open(path, "w") as f:
-        f.write(doc[:m.start()] + new + doc[m.end():])
+        f.write(doc)
     return 0
 
 
