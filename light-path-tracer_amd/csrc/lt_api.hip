@@ -108,6 +108,23 @@ struct Ctx {
     std::vector<EventQuad> pool;
 };
 
+// lt_render's private timing events of a slot, all four or none (a failed creation leaves nothing behind)
+static int slot_events(StreamSlot *sl)
+{
+    if (sl->own_ok) return LT_OK;
+    int made = 0;
+    for (auto &e : sl->own.e) {
+        if (hipEventCreate(&e) != hipSuccess) break;
+        ++made;
+    }
+    if (made != (int)(sizeof(sl->own.e) / sizeof(sl->own.e[0]))) {
+        for (int j = 0; j < made; ++j) (void)hipEventDestroy(sl->own.e[j]);
+        return fail(LT_ERR_HIP, "hipEventCreate failed");
+    }
+    sl->own_ok = true;
+    return LT_OK;
+}
+
 static std::mutex g_mu;
 static Ctx g_ctx[64];
 struct MultiStream { int dev, idx; hipStream_t s; }; // lt_render_multi: one stream per (device, partition)
@@ -886,10 +903,7 @@ extern "C" int lt_render(const lt_camera *cam, const lt_metric *metric, const lt
     auto at = [&](bool want, size_t off) -> void * { return want ? (void *)(base + off) : nullptr; };
     if (bg) HIP_TRY(hipMemcpyAsync(base + o_bg, bg, n_full * bg_channels * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(base + o_stats, 0, LT_STAT_WORDS * 8, s));
-    if (!sl->own_ok) {
-        for (auto &e : sl->own.e) HIP_TRY(hipEventCreate(&e));
-        sl->own_ok = true;
-    }
+    if ((rc = slot_events(sl))) return rc;
     o.timing = 0; // private events: concurrent lt_render_dev(timing = 1) callers keep theirs
     rc = render_dev_impl(cam, metric, &o, (const float *)at(bg != nullptr, o_bg), bg_channels, (float *)at(out_fa, o_fa),
                          (uint16_t *)at(out_w, o_w), (int8_t *)at(out_status, o_st), (uint32_t *)at(out_steps, o_steps),
@@ -992,10 +1006,7 @@ extern "C" int lt_render_multi(const lt_camera *cam, const lt_metric *metric, co
         auto at = [&](bool want, size_t off) -> void * { return want ? (void *)(base + off) : nullptr; };
         if (bg) HIP_TRY(hipMemcpyAsync(base + o_bg, bg, n_full * bg_channels * sizeof(float), hipMemcpyHostToDevice, P.s));
         HIP_TRY(hipMemsetAsync(base + P.o_stats, 0, LT_STAT_WORDS * 8, P.s));
-        if (!P.sl->own_ok) {
-            for (auto &e : P.sl->own.e) HIP_TRY(hipEventCreate(&e));
-            P.sl->own_ok = true;
-        }
+        if ((rc = slot_events(P.sl))) return rc;
         lt_opts op = o;
         op.n_parts = n_gpus; op.part = p; op.stream = (void *)P.s; op.timing = 0;
         op.block_owner = nullptr; op.n_blocks = 0; // lt_render_multi partitions block-cyclically
@@ -1173,7 +1184,9 @@ extern "C" int lt_scatter_rows_dev(const void *d_part, void *d_full, int32_t hei
     if (rc) return rc;
     int64_t rows = lt_local_rows(height, row_block, n_parts, part);
     if (rows < 0 || width <= 0 || elem_bytes <= 0) return fail(LT_ERR_INVALID_ARG, "bad scatter arguments");
+    if (rows > 65535) return fail(LT_ERR_INVALID_ARG, "a partition of %lld rows (at most 65535: grid.y carries the row)", (long long)rows);
     if (rows == 0) return LT_OK;
+    if (!d_part || !d_full) return fail(LT_ERR_INVALID_ARG, "null pointer");
     int64_t row_bytes = (int64_t)width * elem_bytes;
     dim3 grid((unsigned)((row_bytes + 16 * 256 - 1) / (16 * 256)), (unsigned)rows);
     k_scatter_rows<<<grid, 256, 0, (hipStream_t)stream>>>((const uint8_t *)d_part, (uint8_t *)d_full, (int)rows, row_bytes,

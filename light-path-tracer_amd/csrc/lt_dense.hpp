@@ -430,6 +430,7 @@ template <typename T> struct PredictConsts {
     T inv_step, inv_kappa;     // 1 / max_step of the real pass;  1 / (0.9 (rtol_real / rtol_loose)^(1/5))
     int64_t n;
     int32_t max_attempts;
+    int32_t refill_min, chunk; // hand-out of tracks to idle lanes (k_dense_predict)
 };
 
 // the 8-D right-hand side of rhs8_sc in the predictor's arithmetic (float32 by default: a tolerance of 1e-4 is far above
@@ -476,7 +477,22 @@ template <typename T> __device__ __forceinline__ T rms8_t(const T *x)
 __device__ __forceinline__ float fast_pow(float x, float p) { return __builtin_amdgcn_exp2f(p * __builtin_amdgcn_logf(x)); }
 
 // One track per lane; writes the track's key (predicted attempts, clamped).
-// Blocks of 64 tracks are handed out from `head` (nullptr: block = workgroup), as in k_dense_tracks.
+// The loose pass's lengths spread as widely as the real pass's -- a wavefront of 64 consecutive tracks that waits for its
+// longest ran at a lane utilisation of 0.48 -- and there is no predictor for the predictor.  There does not have to be: a
+// key is one 16-bit store at the track's index, so a lane whose track has ended takes the next track of the launch.
+// A wave takes `chunk` track numbers from `head` at a time (DENSE_PRED_CHUNK) and deals them out to its idle lanes (each
+// takes next + its rank among them) whenever at least `refill_min` lanes are idle (DENSE_REFILL_MIN): the set-up of a
+// track (Hairer's initial step: two right-hand sides) then runs for that many lanes at once, and an attempt for more
+// than 64 - refill_min.  Measured at 4 M tracks (tools/scratch/pred_sweep.sh): 3.60 ms block per wave -> 2.68 ms, lane
+// utilisation 0.48 -> 0.74 (what is left: the set-up at partial occupancy, the idle lanes below the threshold, the end of
+// every wave's life); refill_min 1 / 2 / 4 / 8 / 16 / 24: 3.55 / 3.33 / 2.96 / 2.68 / 2.70 / 2.83 ms; chunk 32 / 64 / 128:
+// 2.80 / 2.68 / 2.76 ms.  (One atomic per REFILL instead of per chunk -- 420 k atomics on one address -- took 5.6 ms: the
+// memory side serialises same-address atomics at ~6 ns each, and every wave waits for its own.)
+// head == nullptr: the workgroup's own block of 64 tracks and nothing after it.
+// A track's arithmetic does not depend on the lane or the company it runs in: the keys are those of one block per wave.
+constexpr int DENSE_REFILL_MIN = 8;
+constexpr int DENSE_PRED_CHUNK = 64;
+
 template <typename T>
 __global__ void __launch_bounds__(64) k_dense_predict(PredictConsts<T> k, const double *__restrict__ state0,
                                                       uint16_t *__restrict__ key, unsigned long long *__restrict__ head)
@@ -486,48 +502,89 @@ __global__ void __launch_bounds__(64) k_dense_predict(PredictConsts<T> k, const 
                 A61 = T(9017.0 / 3168), A62 = T(-355.0 / 33), A63 = T(46732.0 / 5247), A64 = T(49.0 / 176), A65 = T(-5103.0 / 18656);
     constexpr T B1 = T(35.0 / 384), B3 = T(500.0 / 1113), B4 = T(125.0 / 192), B5 = T(-2187.0 / 6784), B6 = T(11.0 / 84);
     constexpr T E1 = T(-71.0 / 57600), E3 = T(71.0 / 16695), E4 = T(-71.0 / 1920), E5 = T(17253.0 / 339200), E6 = T(-22.0 / 525), E7 = T(1.0 / 40);
-    int64_t block = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const uint64_t below = (1ull << lane) - 1ull;
+    // the lane's track
+    T y[8], f[8];
+    T h = T(0), t = T(0), pred = T(0), g_in = T(0), g_out = T(0), r_in = T(0), r_out = T(0);
+    int64_t i = 0;
+    int32_t attempts = 0;
+    bool rejected = false, have = false;
+    bool drained = false;          // (wave-uniform) nothing left to hand out
+    int64_t next = 0, next_end = 0; // (wave-uniform) the track numbers the wave holds and has not started yet
+#pragma unroll
+    for (int c = 0; c < 8; ++c) y[c] = f[c] = T(0);
     for (;;) {
-        if (head) {
-            unsigned long long w = 0;
-            if (threadIdx.x == 0) w = atomicAdd(head, 1ull);
-            block = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
-                              (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
-        }
-        if (block * 64 >= k.n) break;
-        const int64_t i = block * 64 + threadIdx.x;
-        if (i < k.n) {
-            T y[8], f[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) y[c] = (T)state0[i * 8 + c];
-            const T r_in = k.r_in, r_out = k.r_out < T(0) ? T(2) * y[1] : k.r_out;
-            rhs8_t(k, y, f);
-            T h;
-            { // Hairer's initial step, as the real pass (at the loose tolerance)
-                T v[8], sc[8], y1[8], f1[8];
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { sc[c] = k.atol + M<T>::abs(y[c]) * k.rtol; v[c] = y[c] / sc[c]; }
-                T d0 = rms8_t(v);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = f[c] / sc[c];
-                T d1 = rms8_t(v);
-                T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : T(0.01) * d0 / d1;
-                h0 = M<T>::min(h0, k.lambda_max);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) y1[c] = y[c] + h0 * f[c];
-                rhs8_t(k, y1, f1);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = (f1[c] - f[c]) / sc[c];
-                T d2 = rms8_t(v) / h0;
-                T dm = M<T>::max(d1, d2);
-                T h1 = dm <= T(1e-15) ? M<T>::max(T(1e-6), h0 * T(1e-3)) : (T)fast_pow(0.01f / (float)dm, 0.2f);
-                h = M<T>::min(M<T>::min(T(100) * h0, h1), k.lambda_max);
+        const uint64_t idle = __ballot(!have);
+        const int n_idle = __popcll(idle);
+        if (!drained && (n_idle >= k.refill_min || n_idle == 64)) {
+            if (next == next_end) { // the wave's chunk of track numbers is used up: take the next one
+                if (head) {
+                    unsigned long long w = 0;
+                    if (lane == 0) w = atomicAdd(head, (unsigned long long)k.chunk);
+                    next = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+                                     (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
+                    next_end = next + k.chunk < k.n ? next + k.chunk : k.n;
+                } else if (next_end == 0) {
+                    next = (int64_t)blockIdx.x * 64;
+                    next_end = next + 64 < k.n ? next + 64 : k.n;
+                } else {
+                    next = next_end = k.n;
+                }
+                if (next >= k.n) { drained = true; next = next_end = k.n; }
             }
-            T t = T(0), pred = T(0);
-            T g_in = y[1] - r_in, g_out = y[1] - r_out;
-            bool rejected = false, ended = false;
-            for (int32_t attempts = 0; attempts < k.max_attempts; ++attempts) {
-                if (!(t < k.lambda_max) || !(h > T(1e-6) * (T(1) + t))) { ended = true; break; } // (a collapsed step size: whatever was predicted so far)
+            const int64_t cand = next + __popcll(idle & below);
+            const int64_t avail = next_end - next;
+            const bool take = !have && cand < next_end;
+            next += n_idle < avail ? n_idle : avail;
+            if (take) {
+                i = cand;
+                have = true;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) y[c] = (T)state0[i * 8 + c];
+                r_in = k.r_in;
+                r_out = k.r_out < T(0) ? T(2) * y[1] : k.r_out;
+                rhs8_t(k, y, f);
+                { // Hairer's initial step, as the real pass (at the loose tolerance)
+                    T v[8], sc[8], y1[8], f1[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { sc[c] = k.atol + M<T>::abs(y[c]) * k.rtol; v[c] = y[c] / sc[c]; }
+                    T d0 = rms8_t(v);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = f[c] / sc[c];
+                    T d1 = rms8_t(v);
+                    T h0 = (d0 < T(1e-5) || d1 < T(1e-5)) ? T(1e-6) : T(0.01) * d0 / d1;
+                    h0 = M<T>::min(h0, k.lambda_max);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) y1[c] = y[c] + h0 * f[c];
+                    rhs8_t(k, y1, f1);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = (f1[c] - f[c]) / sc[c];
+                    T d2 = rms8_t(v) / h0;
+                    T dm = M<T>::max(d1, d2);
+                    T h1 = dm <= T(1e-15) ? M<T>::max(T(1e-6), h0 * T(1e-3)) : (T)fast_pow(0.01f / (float)dm, 0.2f);
+                    h = M<T>::min(M<T>::min(T(100) * h0, h1), k.lambda_max);
+                }
+                t = T(0);
+                pred = T(0);
+                g_in = y[1] - r_in;
+                g_out = y[1] - r_out;
+                rejected = false;
+                attempts = 0;
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (drained) break;
+            continue;
+        }
+        if (have) { // one attempt
+            bool ended = false, finished = false; // finished: the track is over; ended: and the loose pass saw its end
+            if (attempts >= k.max_attempts) {
+                finished = true;
+            } else if (!(t < k.lambda_max) || !(h > T(1e-6) * (T(1) + t))) { // (a collapsed step size: whatever was predicted so far)
+                finished = ended = true;
+            } else {
+                ++attempts;
                 T hh = M<T>::min(h, k.lambda_max - t);
                 T k2[8], k3[8], k4[8], k5[8], k6[8], k7[8], tmp[8], yn[8];
 #pragma unroll
@@ -560,37 +617,39 @@ __global__ void __launch_bounds__(64) k_dense_predict(PredictConsts<T> k, const 
                     T fac = err == err ? (T)(0.9f * fast_pow((float)err, -0.2f)) : T(0.2);
                     h = hh * M<T>::max(T(0.2), fac);
                     rejected = true;
-                    continue;
-                }
-                T fac = err > T(1e-12) ? M<T>::min(T(10), (T)(0.9f * fast_pow((float)err, -0.2f))) : T(10);
-                if (rejected) fac = M<T>::min(T(1), fac);
-                rejected = false;
-                h = hh * fac;
-                const T gn_in = yn[1] - r_in, gn_out = yn[1] - r_out;
-                const bool hit_in = g_in >= T(0) && gn_in <= T(0), hit_out = g_out <= T(0) && gn_out >= T(0);
-                T used = hh;
-                if (hit_in || hit_out) { // the part of the step before the event, by linear interpolation in r
-                    T g0 = hit_in ? g_in : g_out, g1 = hit_in ? gn_in : gn_out;
-                    T fr = g0 != g1 ? g0 / (g0 - g1) : T(1);
-                    used = hh * M<T>::min(M<T>::max(fr, T(0)), T(1));
-                }
-                // steps of the real pass across this one: held by max_step, or by the tolerance
-                const T by_tol = err > T(1e-12) ? (T)fast_pow((float)err, 0.2f) * k.inv_kappa * (used / hh) : T(0);
-                pred += M<T>::max(used * k.inv_step, by_tol);
-                if (hit_in || hit_out) { ended = true; break; }
-                g_in = gn_in; g_out = gn_out;
-                t += hh;
+                } else {
+                    T fac = err > T(1e-12) ? M<T>::min(T(10), (T)(0.9f * fast_pow((float)err, -0.2f))) : T(10);
+                    if (rejected) fac = M<T>::min(T(1), fac);
+                    rejected = false;
+                    h = hh * fac;
+                    const T gn_in = yn[1] - r_in, gn_out = yn[1] - r_out;
+                    const bool hit_in = g_in >= T(0) && gn_in <= T(0), hit_out = g_out <= T(0) && gn_out >= T(0);
+                    T used = hh;
+                    if (hit_in || hit_out) { // the part of the step before the event, by linear interpolation in r
+                        T g0 = hit_in ? g_in : g_out, g1 = hit_in ? gn_in : gn_out;
+                        T fr = g0 != g1 ? g0 / (g0 - g1) : T(1);
+                        used = hh * M<T>::min(M<T>::max(fr, T(0)), T(1));
+                    }
+                    // steps of the real pass across this one: held by max_step, or by the tolerance
+                    const T by_tol = err > T(1e-12) ? (T)fast_pow((float)err, 0.2f) * k.inv_kappa * (used / hh) : T(0);
+                    pred += M<T>::max(used * k.inv_step, by_tol);
+                    if (hit_in || hit_out) finished = ended = true;
+                    g_in = gn_in; g_out = gn_out;
+                    t += hh;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) { y[c] = yn[c]; f[c] = k7[c]; }
+                    for (int c = 0; c < 8; ++c) { y[c] = yn[c]; f[c] = k7[c]; }
+                }
             }
-            // a track the loose pass did not finish within its attempt budget (a photon that orbits the hole for long: a few
-            // per cent of a fan of rays, several times the typical effort) is long: it goes first in its window
-            if (!ended) pred = T(DENSE_KEY_BINS);
-            int kk = pred == pred ? (int)(float)pred : 0;
-            kk = kk < 0 ? 0 : (kk > DENSE_KEY_BINS - 1 ? DENSE_KEY_BINS - 1 : kk);
-            key[i] = (uint16_t)kk;
+            if (finished) {
+                // a track the loose pass did not finish within its attempt budget (a photon that orbits the hole for long: a few
+                // per cent of a fan of rays, several times the typical effort) is long: it goes first in its window
+                if (!ended) pred = T(DENSE_KEY_BINS);
+                int kk = pred == pred ? (int)(float)pred : 0;
+                kk = kk < 0 ? 0 : (kk > DENSE_KEY_BINS - 1 ? DENSE_KEY_BINS - 1 : kk);
+                key[i] = (uint16_t)kk;
+                have = false;
+            }
         }
-        if (!head) break;
     }
 }
 

@@ -1063,7 +1063,8 @@ __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__rest
     const uint8_t *src = part + (int64_t)lrow * row_bytes;
     uint8_t *dst = full + grow * row_bytes;
     int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (i + 16 <= row_bytes && (row_bytes & 15) == 0) {
+    const bool aligned = (((uintptr_t)part | (uintptr_t)full | (uintptr_t)row_bytes) & 15) == 0; // every row of both buffers on 16 B
+    if (i + 16 <= row_bytes && aligned) {
         *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
     } else {
         for (int64_t j = i; j < i + 16 && j < row_bytes; ++j) dst[j] = src[j];
@@ -1083,7 +1084,8 @@ __global__ void k_scatter_rows_indexed(const uint8_t *__restrict__ src_rows, uin
     const uint8_t *src = src_rows + i * row_bytes;
     uint8_t *dst = full + grow * row_bytes;
     int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (b + 16 <= row_bytes && (row_bytes & 15) == 0) {
+    const bool aligned = (((uintptr_t)src_rows | (uintptr_t)full | (uintptr_t)row_bytes) & 15) == 0; // every row of both buffers on 16 B
+    if (b + 16 <= row_bytes && aligned) {
         *reinterpret_cast<uint4 *>(dst + b) = *reinterpret_cast<const uint4 *>(src + b);
     } else {
         for (int64_t j = b; j < b + 16 && j < row_bytes; ++j) dst[j] = src[j];

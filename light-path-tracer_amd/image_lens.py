@@ -318,7 +318,8 @@ def load_lookup_cache(path, key):
 
 
 def save_lookup_cache(path, key, final_alpha, winding):
-    np.savez(path, key=np.array(key), final_alpha=final_alpha, winding=winding)
+    with open(path, "wb") as f:          # (a file object: np.savez would append ".npz" to a bare name, and the next load would miss it)
+        np.savez(f, key=np.array(key), final_alpha=final_alpha, winding=winding)
 
 
 def main(metric=None, M=1.0, a=0.0, r_obs_mult=100.0, psi=(0.0, 0.0), vertical_fov_deg=40.0,

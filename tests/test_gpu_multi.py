@@ -69,3 +69,13 @@ def test_render_multi_on_real_devices():
     many = ltrace.render_multi(cam, met, ltrace.default_opts(precision=32), min(n, 8), want=("fa", "status", "rgba"))
     for k in ("fa", "status", "rgba"):
         assert np.array_equal(one[k], many[k], equal_nan=True), k
+
+
+def test_row_scatter_kernels_against_numpy():
+    """lt_scatter_rows_dev / lt_scatter_rows_indexed_dev byte for byte against numpy indexing (tests/scatter_rows_check.py,
+    in a process of its own: it holds device buffers through torch, and torch's HIP runtime must be the first one a
+    process initialises)."""
+    if _gpus() < 1:
+        pytest.skip("needs a GPU")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "scatter_rows_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -153,6 +153,11 @@ def test_alpha_dedup_and_lookup_cache(tmp_path, capsys):
     assert "Lookup cache hit" in capsys.readouterr().out
     np.testing.assert_array_equal(first, second)
     other = image_lens.main(output_path=str(tmp_path / "c.png"), **dict(kw, a=0.5))     # another metric: a miss, then rewritten
+    bare = str(tmp_path / "cache_without_extension")            # the file is written under the name given, whatever it is
+    image_lens.main(output_path=str(tmp_path / "f.png"), **dict(kw, lookup_cache=bare))
+    capsys.readouterr()
+    image_lens.main(output_path=str(tmp_path / "g.png"), **dict(kw, lookup_cache=bare))
+    assert "Lookup cache hit" in capsys.readouterr().out and os.path.exists(bare)
     assert "cache hit" not in capsys.readouterr().out and not np.array_equal(other, first)
     staged = image_lens.main(output_path=str(tmp_path / "d.png"), staged=True, dedup_alpha=True, a=0.0, r_obs_mult=100.0, synthetic=(96, 64))
     plain = image_lens.main(output_path=str(tmp_path / "e.png"), staged=True, a=0.0, r_obs_mult=100.0, synthetic=(96, 64))
