@@ -775,6 +775,8 @@ static int render_dev_impl(const lt_camera *cam, const lt_metric *metric, const 
         }
     }
     int64_t n_q = (int64_t)c.tiles_x * tiles_y * 64;
+    if (n_q / 64 >= (int64_t)1 << 31) // (the prologue decodes a tile's queue position in 32 bits; 2^31 tiles of records would be 6 TB)
+        return fail(LT_ERR_INVALID_ARG, "frame of %d x %d tiles: more than 2^31 - 1", c.tiles_x, tiles_y);
     double lambda_max = fmax(5000.0, 6.0 * cam->r_obs); // metrics.py:1132
 
     size_t elem = o.precision == 32 ? sizeof(float) : sizeof(double);

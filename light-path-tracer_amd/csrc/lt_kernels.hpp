@@ -64,6 +64,17 @@ __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
     return gb * c.row_block + o;
 }
 
+// The same for the eight rows of a tile that starts at the (wave-uniform) local row tile_row: when row blocks are a
+// multiple of 8 rows -- the default is 16 -- a tile lies inside one block, and block, table entry and base row are
+// scalars; otherwise per lane as above.
+__device__ __forceinline__ int tile_to_global_row(const CamConsts &c, int tile_row, int lrow)
+{
+    if (c.row_block & 7) return local_to_global_row(c, lrow);
+    int b = tile_row / c.row_block;
+    int gb = c.block_list ? c.block_list[b] : b * c.n_parts + c.part;
+    return gb * c.row_block + (lrow - b * c.row_block);
+}
+
 // Queue order of the tiles, so that the slowest rays START FIRST instead of forming the tail of the
 // launch (a ray is a serial chain nothing can shorten, and the slowest take ~50x the mean):
 //   1. the strip of tile columns [strip_x0, strip_x1) the spin axis projects to, every row -- rays
@@ -73,45 +84,48 @@ __device__ __forceinline__ int local_to_global_row(const CamConsts &c, int lrow)
 // Parts 2 and 3 live on the grid with the strip's columns removed (width cw = tiles_x - strip width;
 // hot_x0 / hot_x1 are in those compacted columns).  Both directions of the map are closed-form (no
 // table): K1 needs queue -> tile, K3 tile -> queue.
-__device__ __forceinline__ void queue_pos_to_tile(const CamConsts &c, int64_t pos, int &tx, int &ty)
+// (32-bit arithmetic: the host refuses a frame of 2^31 tiles or more; a 64-bit division costs a wavefront ~120 instructions)
+__device__ __forceinline__ void queue_pos_to_tile(const CamConsts &c, uint32_t pos, int &tx, int &ty)
 {
-    const int sw = c.strip_x1 - c.strip_x0;
-    const int64_t n_strip = (int64_t)sw * c.tiles_y;
+    const uint32_t sw = (uint32_t)(c.strip_x1 - c.strip_x0);
+    const uint32_t n_strip = sw * (uint32_t)c.tiles_y;
     if (pos < n_strip) {
-        ty = (int)(pos / sw);
-        tx = c.strip_x0 + (int)(pos - (int64_t)ty * sw);
+        const uint32_t rowi = pos / sw;
+        ty = (int)rowi;
+        tx = c.strip_x0 + (int)(pos - rowi * sw);
         return;
     }
     pos -= n_strip;
-    const int cw = c.tiles_x - sw;
-    const int hw = c.hot_x1 - c.hot_x0, hh = c.hot_y1 - c.hot_y0;
-    const int64_t n_hot = (int64_t)hw * hh;
+    const uint32_t cw = (uint32_t)c.tiles_x - sw;
+    const uint32_t hw = (uint32_t)(c.hot_x1 - c.hot_x0), hh = (uint32_t)(c.hot_y1 - c.hot_y0);
+    const uint32_t n_hot = hw * hh;
     int cx;
     if (pos < n_hot) {
-        int rowi = (int)(pos / hw);
-        ty = c.hot_y0 + rowi;
-        cx = c.hot_x0 + (int)(pos - (int64_t)rowi * hw);
+        const uint32_t rowi = pos / hw;
+        ty = c.hot_y0 + (int)rowi;
+        cx = c.hot_x0 + (int)(pos - rowi * hw);
     } else {
-        int64_t p = pos - n_hot;
-        const int64_t top = (int64_t)c.hot_y0 * cw; // full rows above the rectangle
-        const int side = cw - hw;                    // tiles per row beside the rectangle
-        const int64_t mid = (int64_t)hh * side;
+        uint32_t p = pos - n_hot;
+        const uint32_t top = (uint32_t)c.hot_y0 * cw; // full rows above the rectangle
+        const uint32_t side = cw - hw;                // tiles per row beside the rectangle
+        const uint32_t mid = hh * side;
         if (p < top) {
-            ty = (int)(p / cw);
-            cx = (int)(p - (int64_t)ty * cw);
+            const uint32_t rowi = p / cw;
+            ty = (int)rowi;
+            cx = (int)(p - rowi * cw);
         } else if (p < top + mid) {
             p -= top;
-            int rowi = (int)(p / side), o = (int)(p - (int64_t)rowi * side);
-            ty = c.hot_y0 + rowi;
-            cx = o < c.hot_x0 ? o : o + hw;
+            const uint32_t rowi = p / side, o = p - rowi * side;
+            ty = c.hot_y0 + (int)rowi;
+            cx = (int)o < c.hot_x0 ? (int)o : (int)(o + hw);
         } else {
             p -= top + mid;
-            int rowi = (int)(p / cw);
-            ty = c.hot_y1 + rowi;
-            cx = (int)(p - (int64_t)rowi * cw);
+            const uint32_t rowi = p / cw;
+            ty = c.hot_y1 + (int)rowi;
+            cx = (int)(p - rowi * cw);
         }
     }
-    tx = cx < c.strip_x0 ? cx : cx + sw;
+    tx = cx < c.strip_x0 ? cx : cx + (int)sw;
 }
 
 __device__ __forceinline__ int64_t tile_to_queue_pos(const CamConsts &c, int tx, int ty)
@@ -132,13 +146,18 @@ __device__ __forceinline__ int64_t tile_to_queue_pos(const CamConsts &c, int tx,
     return n_strip + n_hot + ((int64_t)ty * cw + cx - before);
 }
 
-__device__ __forceinline__ void q_to_pixel(const CamConsts &c, int64_t q, int &ix, int &lrow)
+// The 64 rays of a wavefront are one tile (q = workgroup * 256 + work-item, wavefronts of 64): the tile's queue position
+// is the same in every lane.  Said with readfirstlane, the decode above -- divisions by run-time widths -- runs once per
+// wavefront on the scalar unit instead of 64-wide on the vector unit, where it was a fifth of the prologue's instructions.
+__device__ __forceinline__ void q_to_pixel(const CamConsts &c, int64_t q, int &ix, int &lrow, int &tile_row)
 {
-    int lane = (int)(q & 63);
+    const int lane = (int)(q & 63);
+    const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(q >> 6));
     int tx, ty;
-    queue_pos_to_tile(c, q >> 6, tx, ty);
+    queue_pos_to_tile(c, pos, tx, ty);
     ix = tx * 8 + (lane & 7);
-    lrow = ty * 8 + (lane >> 3);
+    tile_row = ty * 8; // (wave-uniform)
+    lrow = tile_row + (lane >> 3);
 }
 
 __device__ __forceinline__ int64_t pixel_to_q(const CamConsts &c, int ix, int lrow)
@@ -232,10 +251,10 @@ __global__ void __launch_bounds__(256) k_prologue_camera(CamConsts c, MetricCons
 {
     int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= n_q) return;
-    int ix, lrow;
-    q_to_pixel(c, q, ix, lrow);
+    int ix, lrow, tile_row;
+    q_to_pixel(c, q, ix, lrow, tile_row);
     if (ix >= c.W || lrow >= c.trace_rows) { store_ic<T>(ic, q, 0, 0, 0, FLAG_PAD); return; }
-    int grow = local_to_global_row(c, lrow);
+    int grow = tile_to_global_row(c, tile_row, lrow);
     double alpha, theta = 0.0;
     if (m.kind == 0) alpha = pixel_alpha(c, ix, grow); // a spherically symmetric metric never looks at theta
     else pixel_angles(c, ix, grow, alpha, theta);
