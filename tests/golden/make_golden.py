@@ -148,8 +148,11 @@ def trace_grid(pool, kind, M, a, r_obs, n, refine_mode, fov_deg=40.0, theta_obs=
                 n_half=nh, rhs_evals=ev)
 
 
+OUT_DIR = HERE      # --verify writes into a temporary directory instead and compares
+
+
 def save(name, **arrs):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT_DIR, name)
     np.savez_compressed(path, **arrs)
     print(f"  wrote {name} ({os.path.getsize(path)/1024:.0f} KiB)")
 
@@ -324,7 +327,7 @@ def f7_scalars():
     out["schw_ic8"] = [float(x) for x in s0]
     out["schw_rhs8"] = [float(x) for x in S.geodesic_equations(0.0, s0)]
     out["schw_ic8_none"] = S.initial_conditions(50.0, np.pi / 2 + 1e-9) is None or "not none"
-    with open(os.path.join(HERE, "scalars.json"), "w") as f:
+    with open(os.path.join(OUT_DIR, "scalars.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("  wrote scalars.json")
 
@@ -339,7 +342,7 @@ def f8_ivp():
             rows.append(dict(deg=deg, outcome=oc, r_final=float(sol.y[1, -1]),
                              phi_final=float(sol.y[3, -1]), nfev=int(sol.nfev)))
         out[name] = rows
-    with open(os.path.join(HERE, "solve_ivp.json"), "w") as f:
+    with open(os.path.join(OUT_DIR, "solve_ivp.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("  wrote solve_ivp.json")
 
@@ -440,11 +443,47 @@ RAY_SETS = [
 ]
 
 
+def verify(todo):
+    """The committed fixtures are what the reference under LT_REFERENCE computes today: regenerate, compare, write nothing
+    into the tree.  (tests/test_oracle_golden.py runs this where the reference is present.)"""
+    global OUT_DIR
+    import tempfile
+    makers = {"F1": f1_rhs, "F2": f2_ic, "F6": f6_psi, "F7": f7_scalars, "F8": f8_ivp, "F9": f9_shadow, "F10": f10_dense, "F4": f4_lookup}
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT_DIR = tmp
+        for k in todo:
+            makers[k]()
+        for name in sorted(os.listdir(tmp)):
+            new, old = os.path.join(tmp, name), os.path.join(HERE, name)
+            if not os.path.exists(old):
+                bad.append(f"{name}: not committed")
+            elif name.endswith(".npz"):
+                with np.load(new, allow_pickle=False) as a, np.load(old, allow_pickle=False) as b:
+                    if sorted(a.files) != sorted(b.files):
+                        bad.append(f"{name}: arrays {sorted(a.files)} != {sorted(b.files)}")
+                    else:
+                        bad += [f"{name}[{f}] differs" for f in a.files
+                                if not (a[f].shape == b[f].shape and (np.array_equal(a[f], b[f], equal_nan=True) if a[f].dtype.kind == "f"
+                                                                        else np.array_equal(a[f], b[f])))]
+            else:
+                with open(new) as fa, open(old) as fb:
+                    if json.load(fa) != json.load(fb):
+                        bad.append(f"{name}: JSON differs")
+    OUT_DIR = HERE
+    print("verify:", "ok, " + ", ".join(todo) + " reproduce" if not bad else "; ".join(bad))
+    return 1 if bad else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--new-only", action="store_true", help="F3: only the ray sets whose file does not exist yet")
+    ap.add_argument("--verify", action="store_true", help="regenerate the quick sets (default F1,F2,F6,F7, or --only) into a temporary "
+                                                          "directory and compare them with the committed files, value for value")
     args = ap.parse_args()
+    if args.verify:
+        return verify(args.only.split(",") if args.only else ["F1", "F2", "F6", "F7"])
     todo = args.only.split(",") if args.only else ["F1", "F2", "F3", "F4", "F6", "F7", "F8", "F9", "F10"]
     t0 = time.time()
     if "F1" in todo:
@@ -469,4 +508,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

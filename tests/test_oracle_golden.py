@@ -200,3 +200,19 @@ def test_dense_tracks_match_solve_ivp(golden_dir):
         else:  # the last point sits on the event radius
             assert abs(y[1, -1] - (r_in if status == 1 else r_out)) < 1e-9
         assert (1 if y[1, -1] > 1.1 * r_in else -1) == g["outcome"][i]
+
+
+def test_committed_fixtures_reproduce_from_the_reference(golden_dir):
+    """The fixtures are the reference's outputs, not the build's: where the reference is present (the build container;
+    it never travels to the GPU box) tests/golden/make_golden.py --verify runs its functions again and compares every
+    array of the quick sets (F1 right-hand side, F2 initial conditions, F6 camera frame, F7 scalar known answers, F8
+    solve_ivp outcomes, F9 analytic shadow, F10 dense solve_ivp tracks) with the committed files, value for value."""
+    import subprocess
+    import sys
+    ref = os.environ.get("LT_REFERENCE", "/root/reference")
+    if not os.path.exists(os.path.join(ref, "metrics.py")):
+        pytest.skip("the reference is not on this machine")
+    env = dict(os.environ, MPLBACKEND="Agg", PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(golden_dir, "make_golden.py"), "--verify", "--only", "F1,F2,F6,F7,F8,F9,F10"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "verify: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]

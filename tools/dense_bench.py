@@ -30,11 +30,17 @@ PEAK_F64_ISSUE = 1024 * 2.4e9 / 4      # wave-instructions per second: 1024 SIMD
 def roofline(key, ms_tracks):
     """k_dense_tracks against the float64 VALU issue peak, from the SQ_INSTS_VALU count committed for this workload and
     this build (profiles/valu_counts.json, written by tools/prof_dense.sh); None without a matching record."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "valu_counts.json")) as f:
-            rec = (json.load(f).get("workloads") or {}).get(key)
-    except (OSError, ValueError):
-        rec = None
+    rec = None
+    # LT_VALU_RECORD: the record tools/prof_dense.sh has just written for this build (before it is merged into profiles/)
+    for path, pick in ((os.environ.get("LT_VALU_RECORD"), lambda d: d.get(key)),
+                       (os.path.join(ROOT, "profiles", "valu_counts.json"), lambda d: (d.get("workloads") or {}).get(key))):
+        if not path or rec:
+            continue
+        try:
+            with open(path) as f:
+                rec = pick(json.load(f))
+        except (OSError, ValueError):
+            rec = None
     if not rec:
         return None
     fresh = rec.get("build_id") == ltrace.build_id()

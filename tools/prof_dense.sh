@@ -35,5 +35,7 @@ if "SQ_INSTS_VALU" in agg and dur:
     json.dump({f"dense_tracks|kerr_a{float(a)}|n{int(n)}|mp{int(mp)}|binning{int(b)}": rec}, open(os.path.join(out, "valu_record.json"), "w"), indent=1)
     print("valu record:", rec)
 PY
-cat "$OUT/bench.json" >> "$OUT/summary.txt"
+# the benchmark line once more WITHOUT the profiler, priced with the record just written (same build, same box)
+LT_VALU_RECORD="$OUT/valu_record.json" python3 tools/dense_bench.py "$@" > "$OUT/bench_plain.json" 2>/dev/null || cp "$OUT/bench.json" "$OUT/bench_plain.json"
+cat "$OUT/bench_plain.json" >> "$OUT/summary.txt"
 tail -40 "$OUT/summary.txt"

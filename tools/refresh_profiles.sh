@@ -38,6 +38,7 @@ if [ "${1:-}" = measure ]; then
     bash tools/prof_dense.sh binned 4194304 224 0.9 1 > /dev/null 2>&1
     bash tools/prof_dense.sh caller 4194304 224 0.9 -1 > /dev/null 2>&1
     bash tools/pmc_dense.sh 4194304 224 > /dev/null 2>&1
+    python3 tools/merge_dense_records.py
     for b in -1 0; do for n in 65536 1048576 4194304; do python3 tools/dense_bench.py $n 224 0.9 $b 2>/dev/null; done; done > $G/dense_bench.log
     python3 tools/dense_lane_stats.py > $G/dense_lane_stats.log 2>&1
     python3 -m pytest tests/test_gpu_dense.py -m gpu -q -s -k "batch_matches or length_predictor" 2>&1 | grep "oracle\|lane-utilisation" > $G/dense_oracle.log
@@ -77,14 +78,7 @@ for k, v in d.get('projected_ranks', {}).items():
       echo "## memory-pipe counters of k_dense_tracks, caller order against length-binned (tools/pmc_dense.sh)"; cat $G/pmc_dense/summary.txt
       echo "## throughput by batch size: length_binning -1 (caller order) and 0 (automatic)"; cat $G/dense_bench.log
       grep -v amdgpu $G/dense_lane_stats.log; cat $G/dense_oracle.log; } > $P/${R}_dense_tracks.txt
-    python3 - <<'PY'
-import glob, json
-p = "profiles/valu_counts.json"
-d = json.load(open(p))
-for f in glob.glob("gpurun_out/prof_dense_*/valu_record.json"):
-    d["workloads"].update(json.load(open(f)))
-json.dump(d, open(p, "w"), indent=1)
-PY
+    python3 tools/merge_dense_records.py
     ls -la $P | grep $R
 else
     echo "usage: $0 measure [quick]|collect"; exit 2
