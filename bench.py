@@ -197,7 +197,8 @@ def cpu_baseline(args, fov, integrator):
     dt = time.perf_counter() - t0
     return {"value": round(n * n / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads,
             "host_cpus_visible": os.cpu_count(),
-            "kind": "port (perf build: gcc " + " ".join(oracle.PERF_FLAGS[:3]) + ", built on this host)",
+            "kind": "port",
+            "build": "oracle/lt_oracle.c, gcc " + " ".join(oracle.PERF_FLAGS[:3]) + ", built on this host (perf build)",
             "sample": f"{n}x{n} rays = every {stride}th pixel (x and y) of the {args.size}x{args.size} frame, "
                       f"oracle {kw['integrator']} float64 + OpenMP on {threads} threads (the job's CPU quota), {dt:.1f} s",
             "mean_rhs_evals_per_ray": round(float(r["evals"].mean()), 1)}

@@ -43,7 +43,7 @@ def test_north_star_line_has_the_contract_fields_and_an_honest_roofline():
     assert d["pipelined"]["frames_in_flight"] == 3 and d["pipelined"]["value"] > 0.9 * d["value"]
     assert d["chain_floor"]["longest_ray_steps"] > 2000 and d["chain_floor"]["alone_ms"] < r["avg_launch_ms"]
     assert 5.0 < d["end_to_end_ms"]["pinned_dst_ms"] < 40.0
-    assert d["cpu_baseline"]["unit"] == "Mrays/s" and d["cpu_baseline"]["cores"] >= 1 and "perf build" in d["cpu_baseline"]["kind"]
+    assert d["cpu_baseline"]["unit"] == "Mrays/s" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port" and "perf build" in d["cpu_baseline"]["build"]
     assert d["ranks"]["rccl_world"] == 1 and d["ranks"]["devices"][0]["rank"] == 0
     assert d["config"]["balance"] == {"requested": "auto", "used": "cyclic"}
     # the reference's production path (DP45 float64, the plugin default) is measured in the same line, with its own
