@@ -28,10 +28,7 @@ using namespace lt;
 namespace lt {
 extern template __global__ void k_kerr_direct<float, Rk4<float>>(KerrConsts<float>, const typename Vec4<float>::type *__restrict__,
                                                                  typename Vec4<float>::type *__restrict__, typename Vec4<float>::type *__restrict__,
-                                                                 int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__, unsigned long long *);
-extern template __global__ void k_kerr_direct<float, Rk4<float>, true>(KerrConsts<float>, const typename Vec4<float>::type *__restrict__,
-                                                                 typename Vec4<float>::type *__restrict__, typename Vec4<float>::type *__restrict__,
-                                                                 int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__, unsigned long long *);
+                                                                 int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,9 +180,8 @@ static void release(Grow &g)
 // Workspace layout: 256 B of control words (queue head) | STAT_SLOTS x 8 partial counters of the epilogue | ic[n_q] |
 // fin0[n_q] | fin1[n_q], each a 4-vector of T.  The partial counters are zero between frames (zeroed when the buffer
 // is allocated, and again by k_stats_reduce after it has read them).
-constexpr size_t WS_LIST_OFF = 256 + (size_t)STAT_SLOTS * 8 * sizeof(unsigned long long); // k_kerr_direct<COOL>'s hand-off list
-constexpr size_t WS_CTRL_BYTES = WS_LIST_OFF + (size_t)QC_LIST_CAP * sizeof(unsigned long long);
-struct Workspace { unsigned long long *head; unsigned long long *partials; unsigned long long *list; void *ic, *fin0, *fin1; };
+constexpr size_t WS_CTRL_BYTES = 256 + (size_t)STAT_SLOTS * 8 * sizeof(unsigned long long);
+struct Workspace { unsigned long long *head; unsigned long long *partials; void *ic, *fin0, *fin1; };
 
 static int get_workspace(hipStream_t stream, size_t n_q, size_t elem, Workspace *w)
 {
@@ -199,7 +195,6 @@ static int get_workspace(hipStream_t stream, size_t n_q, size_t elem, Workspace 
     char *base = (char *)sl->ws.p;
     w->head = (unsigned long long *)base;
     w->partials = (unsigned long long *)(base + 256);
-    w->list = (unsigned long long *)(base + WS_LIST_OFF);
     w->ic = base + WS_CTRL_BYTES;
     w->fin0 = base + WS_CTRL_BYTES + n_q * vec;
     w->fin1 = base + WS_CTRL_BYTES + 2 * n_q * vec;
@@ -584,7 +579,11 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
             static const int k2_block = [] { int b = env_int("LT_K2_BLOCK", 64);
                                              return (b == 64 || b == 128 || b == 256) ? b : 64; }();
             unsigned kgrid = (unsigned)((n_q + k2_block - 1) / k2_block);
-            static const int long_iters = env_int("LT_D_LONG", 1024);
+            // steps after which a wavefront is "long" (ghost lanes, lone-wave step form, issue priority).  384: with the packed
+            // lone-wave step of round 2 an earlier switch pays on chain-bound launches -- 2048^2 4.19 -> 4.10 ms, one rank of 8
+            // 4.00 -> 3.95, of 4 4.18 -> 4.12 -- and leaves the 4096^2 frame where it was (10.75 / 10.73 ms); 128 costs that
+            // frame 1.5 % (profiles/r03_xcd_clock.txt, tools/scratch/d_long_sweep.sh)
+            static const int long_iters = env_int("LT_D_LONG", 384);
             // Tiles are handed out from a queue head to a grid that fills the chip once (k_kerr_direct); LT_D_PERSIST=0
             // or wider workgroups: one workgroup per tile, as in round 1.
             static const int persist = env_int("LT_D_PERSIST", 1);
@@ -598,40 +597,18 @@ static int launch_integrate(const MetricConsts &mc, const lt_opts &o, double lam
                 if (dp45 && !exact) {
                     if (want_queue_head) resident_grid(resident_slots<k_kerr_direct<T, Dp45<T>>>());
                     if (head) HIP_TRY(hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-                    k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats, head, nullptr);
+                    k_kerr_direct<T, Dp45<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats, head);
                 }
                 if (exact) {
                     if (want_queue_head) resident_grid(resident_slots<k_kerr_direct<T, Dp45<T, true>>>());
                     if (head) HIP_TRY(hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
-                    k_kerr_direct<T, Dp45<T, true>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats, head, nullptr);
+                    k_kerr_direct<T, Dp45<T, true>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)(long_iters / 3), sd.dev, kstats, head);
                 }
             }
             if (!dp45) {
                 if (want_queue_head) resident_grid(resident_slots<k_kerr_direct<T, Rk4<T>>>());
-                // The cool XCD of the serial chains (lt_kernels.hpp): a launch whose bulk is short against the longest chains --
-                // fewer than LT_COOL_ROUNDS tiles per resident wavefront -- takes the variant of the kernel whose long rays move
-                // to servers on an XCD that does nothing else.  Longer launches take the plain kernel: their chains end long
-                // before their bulk does.
-                static const int cool_mode = env_int("LT_COOL_XCD", 0);
-                static const int cool_rounds = env_int("LT_COOL_ROUNDS", 12);
-                bool cool = false;
-                if constexpr (sizeof(T) == 4) {
-                    const unsigned long long horizon = (unsigned long long)(cool_rounds > 0 ? cool_rounds : 0) * kgrid * (unsigned)(k2_block / 64);
-                    cool = head && cool_mode > 0 && (unsigned long long)(n_q / 64) < horizon;
-                    if (cool) { // (its own occupancy: the grid fills the chip once with THIS kernel's wavefronts)
-                        const int slots = resident_slots<k_kerr_direct<T, Rk4<T>, true>>();
-                        if (slots > 0 && (unsigned)slots < kgrid) kgrid = (unsigned)slots;
-                    }
-                }
-                if (head)
-                    k_queue_setup<<<cool ? 16 : 1, 256, 0, s>>>(head, w.list, (unsigned long long)kgrid * (unsigned)(k2_block / 64),
-                                                                      cool ? (1ull | (unsigned long long)env_int("LT_COOL_SERVERS", QC_MAX_SERVERS) << 8) : 0ull);
-                if constexpr (sizeof(T) == 4) {
-                    if (cool)
-                        k_kerr_direct<T, Rk4<T>, true><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats, head, w.list);
-                }
-                if (!cool)
-                    k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats, head, nullptr);
+                if (head) HIP_TRY(hipMemsetAsync(head, 0, sizeof(unsigned long long), s));
+                k_kerr_direct<T, Rk4<T>><<<kgrid, k2_block, 0, s>>>(k, (const V *)w.ic, (V *)w.fin0, (V *)w.fin1, n_q, (uint32_t)long_iters, sd.dev, kstats, head);
             }
         } else {
             int cus;

@@ -621,8 +621,7 @@ __device__ __forceinline__ T kerr_rk4_h(const KerrConsts<T> &k, const RayConsts<
 }
 
 // Event codes carried from the integrate kernel to the epilogue.
-enum : int { EV_MAXRANGE = 2, EV_ESCAPED = 1, EV_CAPTURED = -1, EV_INVALID = 0, EV_PAD = 3, EV_RUNNING = 4,
-              EV_HANDED_OFF = 5 /* k_kerr_direct<COOL>: the ray went to a server of XCD 0; never stored */ };
+enum : int { EV_MAXRANGE = 2, EV_ESCAPED = 1, EV_CAPTURED = -1, EV_INVALID = 0, EV_PAD = 3, EV_RUNNING = 4 };
 
 // Everything one ray carries between steps (registers).
 template <typename T> struct RayState {

@@ -20,8 +20,5 @@
 namespace lt {
 template __global__ void k_kerr_direct<float, Rk4<float>>(KerrConsts<float>, const typename Vec4<float>::type *__restrict__,
                                                           typename Vec4<float>::type *__restrict__, typename Vec4<float>::type *__restrict__,
-                                                          int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__, unsigned long long *);
-template __global__ void k_kerr_direct<float, Rk4<float>, true>(KerrConsts<float>, const typename Vec4<float>::type *__restrict__,
-                                                          typename Vec4<float>::type *__restrict__, typename Vec4<float>::type *__restrict__,
-                                                          int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__, unsigned long long *);
+                                                          int64_t, uint32_t, uint4 *__restrict__, uint64_t *__restrict__, unsigned long long *__restrict__);
 }

@@ -377,141 +377,6 @@ template <typename S> __device__ __forceinline__ void take_from_lane(S &s, uint3
     __builtin_memcpy(&s, w, sizeof(S));
 }
 
-// A cool XCD for the serial chains (k_kerr_direct<..., COOL = true>: a queue head, an integrator with ghost lanes).
-// Measured (tools/scratch/xcd_clock_probe.hip): the shader clock is PER XCD.  One busy wavefront on an XCD whose other
-// wavefronts are idle runs at 2 418-2 426 MHz while the seven other XCDs run the bulk flat out (and those then hold
-// 2.1-2.3 GHz instead of 1.9-2.1: the idle XCD's share of the power budget goes to them); the same wavefront on an XCD
-// that runs bulk beside it gets 1.9-2.2 GHz.  A launch whose end is one ray of thousands of serial steps
-// therefore wants that ray on an XCD that does nothing else -- but which ray that is only shows while it is traced.  So
-// the long rays MOVE:
-//   * the first QC_MAX_SERVERS wavefronts of XCD 0 take no tile at all: they are servers, asleep until rays arrive;
-//   * every other wavefront works through the tile queue as before, but a ray still running after `long_iters` steps is
-//     handed off instead of being carried through the wave's ghost-lane phase: its state goes into its final-record
-//     slot (event = running) and its ray record (affine parameter, retry step), its index into a list, and the
-//     wavefront takes its next tile -- on seven XCDs nothing is ever alone on a SIMD waiting for one ray;
-//   * a server takes whatever the list holds into its idle lanes (up to 64 rays of any tiles), runs them in the
-//     lone-wave form of the step with its empty lanes as ghosts, stores every ray as it ends, refills, and leaves when
-//     no wavefront that could still hand off is left and the list is empty;
-//   * the other wavefronts of XCD 0 work on tiles until the first ray has been handed off, then leave: from there on
-//     the XCD holds the servers and nothing else.
-// A ray's arithmetic does not depend on the lane or the company it runs in (the byte-identity tests between schedules,
-// ghost phases and partitions rest on that), and (state, affine parameter, retry step, step count) is all of a ray:
-// the outputs are those of the plain kernel, byte for byte (tests/test_gpu_ghost_lanes.py).
-// Used for launches whose bulk is short against the chains (the host decides, lt_api.hip); the plain kernel is not touched.
-// Memory ordering: list entries are published with release and read with acquire at agent scope (the XCDs have their own
-// L2s); the busy count likewise, so that a server that sees it at zero also sees every reservation made before.
-// The queue's control words (unsigned long long, behind `head`), written by k_queue_setup before every launch:
-constexpr int QC_HEAD = 0,     // tile queue
-              QC_HO_TAIL = 1,  // list entries reserved by wavefronts handing rays off
-              QC_HO_HEAD = 2,  // list entries claimed by servers
-              QC_BUSY = 3,     // wavefronts that may still hand off (starts at the grid's wavefront count)
-              QC_CFG = 4,      // 1: the mode is on
-              QC_SERVERS = 5,  // wavefronts of XCD 0 that have reported in (the first QC_MAX_SERVERS serve)
-              QC_WORDS = 6;
-constexpr int QC_MAX_SERVERS = 16;
-constexpr int QC_LIST_CAP = 16384; // rays that can be in flight between a hand-off and its server; beyond it a wave keeps its ray
-
-__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; } // HW_REG_XCC_ID[3:0]
-
-// A server of the cool XCD (see above): rays arrive through `list`, each with its state in its final-record slot and in
-// its ray record.  Lanes without a ray shadow the first lane that has one (ghost lanes: the wavefront keeps every lane
-// enabled, k_kerr_direct), so the loop is the ghost-lane phase of k_kerr_direct with a refill in front.
-template <typename T, typename Integ>
-__device__ __forceinline__ void serve_long_rays(const KerrConsts<T> &k, typename Vec4<T>::type *ic, typename Vec4<T>::type *fin0,
-                                                typename Vec4<T>::type *fin1, unsigned long long *head, unsigned long long *list,
-                                                uint64_t *kstats)
-{
-    using V4 = typename Vec4<T>::type;
-    const int lane = (int)(threadIdx.x & 63u);
-    const uint64_t below = (1ull << lane) - 1ull;
-    auto word = [&](int i, int order) -> unsigned long long {
-        return order == 0 ? __hip_atomic_load(head + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : __hip_atomic_load(head + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    auto bcast64 = [&](unsigned long long w) -> int64_t {
-        return (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) | (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
-    };
-    WaveMeter meter;
-    meter.begin(kstats, 1); // (not one of the wavefronts whose clock is sampled: a server's is not the bulk's)
-    __builtin_amdgcn_s_setprio(3);
-    typename Integ::State st;
-    st.y.r = k.r_obs; st.y.th = k.theta_obs; st.y.ph = T(0); st.y.pr = T(0); st.y.pth = T(0);
-    st.lam = T(0); st.h_retry = T(0); st.steps = 0;
-    RayConsts<T> rc = make_ray_consts(k, T(0), false);
-    bool have = false;
-    int64_t q = 0;
-    T p_phi = T(0);
-    uint32_t it = 0;
-    for (;;) {
-        // ---- refill: idle lanes take what the list holds
-        const uint64_t idle = __builtin_amdgcn_ballot_w64(!have);
-        if (idle) {
-            unsigned long long h0 = 0, cnt = 0;
-            if (lane == 0) {
-                for (;;) {
-                    const unsigned long long h = word(QC_HO_HEAD, 0);
-                    unsigned long long t = word(QC_HO_TAIL, 0);
-                    if (t > (unsigned long long)QC_LIST_CAP) t = (unsigned long long)QC_LIST_CAP;
-                    if (h >= t) break;
-                    unsigned long long want = (unsigned long long)__builtin_popcountll(idle);
-                    if (want > t - h) want = t - h;
-                    unsigned long long expect = h;
-                    if (__hip_atomic_compare_exchange_strong(head + QC_HO_HEAD, &expect, h + want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)) { h0 = h; cnt = want; break; }
-                }
-            }
-            const int64_t first = bcast64(h0), n_new = bcast64(cnt);
-            const int64_t rank = (int64_t)__builtin_popcountll(idle & below);
-            if (!have && rank < n_new) {
-                unsigned long long v;
-                do { v = __hip_atomic_load(list + first + rank, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while (v == 0ull); // (reserved, being written)
-                __hip_atomic_store(list + first + rank, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                q = (int64_t)(v - 1ull);
-                const V4 a = fin0[q], b = fin1[q], c = ic[q];
-                st.y.r = a.x; st.y.th = a.y; st.y.ph = a.z; st.y.pr = a.w; st.y.pth = b.x;
-                st.steps = (uint32_t)b.w;
-                st.lam = c.x; st.h_retry = c.y;
-                p_phi = c.z;
-                rc = make_ray_consts(k, p_phi, ((int)c.w & FLAG_REFINE) != 0);
-                have = true;
-            }
-        }
-        if (!wave_any(have)) {
-            // nothing to do: leave when nobody can hand off any more and everything handed off has been claimed
-            if (word(QC_BUSY, 1) == 0ull) {
-                unsigned long long t = word(QC_HO_TAIL, 0);
-                if (t > (unsigned long long)QC_LIST_CAP) t = (unsigned long long)QC_LIST_CAP;
-                if (word(QC_HO_HEAD, 0) >= t) break;
-            } else {
-                __builtin_amdgcn_s_sleep(64);
-            }
-            continue;
-        }
-        // ---- lanes without a ray shadow the first lane that has one
-        const uint32_t lead = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(have));
-        take_from_lane(st, lead, !have);
-        take_from_lane(rc, lead, !have);
-        // ---- run until a ray ends (then store it, look at the list again, re-seat the ghosts)
-        for (uint32_t n = 1;; ++n) {
-            it += Integ::streak_lone(k, rc, st, 64u);
-            const int e = Integ::advance(k, rc, st);
-            ++it;
-            if (wave_any(e != EV_RUNNING)) {
-                if (have & (e != EV_RUNNING)) {
-                    store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, p_phi, e, st.steps);
-                    have = false;
-                }
-                break;
-            }
-            // a look at the list now and then (an iteration is up to 65 steps, ~30 us): a ray that arrives while every
-            // server is busy must not wait for one of THEIR rays to end
-            if ((n & 3u) == 0u && word(QC_HO_TAIL, 0) > word(QC_HO_HEAD, 0)) break;
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    meter.end(kstats, it);
-}
-
 // Direct schedule: one work-item per ray, a wavefront = one 8x8 tile.
 //
 // Ghost lanes (integrators with Integ::GHOST_LANES).  A wavefront still running after `long_iters` iterations hosts
@@ -532,54 +397,26 @@ __device__ __forceinline__ void serve_long_rays(const KerrConsts<T> &k, typename
 // chip idle on average -- and every finished wave left its slot empty until the dispatcher had set up the next one
 // (4.7 of 5 slots occupied).  A wave that takes the next tile itself does neither.  `head` == nullptr: one tile per
 // workgroup, tile = workgroup index (the batch twins' short launches, LT_D_PERSIST=0).
-template <typename T, typename Integ, bool COOL = false>
+template <typename T, typename Integ>
 __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(KerrConsts<T> k_in, const typename Vec4<T>::type *__restrict__ ic,
                                                          typename Vec4<T>::type *__restrict__ fin0,
                                                          typename Vec4<T>::type *__restrict__ fin1, int64_t n_q,
                                                          uint32_t long_iters, uint4 *__restrict__ stamps,
-                                                         uint64_t *__restrict__ kstats, unsigned long long *__restrict__ head, unsigned long long *list)
+                                                         uint64_t *__restrict__ kstats, unsigned long long *__restrict__ head)
 {
     KerrConsts<T> k = k_in;
     pin_consts(k);
     const int lane = (int)(threadIdx.x & 63u);
     int64_t tile = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    auto take = [&](unsigned long long *p) -> int64_t { // the next position of a queue (one atomic per wavefront)
-        unsigned long long w = 0;
-        if (lane == 0) w = atomicAdd(p, 1ull);
-        return (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
-                         (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
-    };
-    using V4 = typename Vec4<T>::type;
-    // 0: plain.  COOL: 1 a wavefront that hands its long rays off, 2 the same on XCD 0 (leaves at the first hand-off)
-    int role = 0;
-    if constexpr (COOL && Integ::GHOST_LANES) {
-        const unsigned long long cfg = head ? __hip_atomic_load(head + QC_CFG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        if (cfg != 0ull) {
-            role = 1;
-            if (xcc_id() == 0) {
-                role = 2;
-                if (take(head + QC_SERVERS) < (int64_t)(cfg >> 8)) {
-                    if (lane == 0) __hip_atomic_fetch_add(head + QC_BUSY, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    serve_long_rays<T, Integ>(k, const_cast<V4 *>(ic), fin0, fin1, head, list, kstats);
-                    return;
-                }
-            }
-        }
-    }
-    auto leave = [&]() { // a wavefront that could have handed off is gone
-        if constexpr (COOL) {
-            if (role != 0 && lane == 0) __hip_atomic_fetch_add(head + QC_BUSY, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
     for (;;) {
     if (head) {
-        if constexpr (COOL) {
-            if (role == 2 && __hip_atomic_load(head + QC_HO_TAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) { leave(); return; }
-        }
-        tile = take(head);
+        unsigned long long w = 0;
+        if (lane == 0) w = atomicAdd(head, 1ull);
+        tile = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
+                         (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
     }
     const int64_t q = tile * 64 + lane;
-    if (q >= n_q) { leave(); return; } // n_q is a multiple of 64: the whole wave leaves (queue empty, or a workgroup past the end)
+    if (q >= n_q) return; // n_q is a multiple of 64: the whole wave leaves (queue empty, or a workgroup past the end)
     uint64_t t0 = stamps ? wave_clock() : 0, c0 = stamps ? __builtin_amdgcn_s_memtime() : 0;
     WaveMeter meter;
     meter.begin(kstats, tile);
@@ -614,31 +451,10 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
     }
     uint32_t steps = st.steps;
     bool real = ev == EV_RUNNING; // only with ghost lanes: this lane's ray is still running
-    if constexpr (COOL && Integ::GHOST_LANES) {
-        // hand the rays that are still running to the servers of XCD 0 (if any has reported in, and while the list has room)
-        if (role != 0 && wave_any(real) &&
-            __hip_atomic_load(head + QC_SERVERS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
-            const uint64_t m = __builtin_amdgcn_ballot_w64(real);
-            unsigned long long w = 0;
-            if (lane == 0) w = atomicAdd(head + QC_HO_TAIL, (unsigned long long)__builtin_popcountll(m));
-            const int64_t base = (int64_t)(((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(w >> 32)) << 32) |
-                                           (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)w));
-            const int64_t slot = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-            if (real && slot < QC_LIST_CAP) {
-                store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, EV_RUNNING, steps);
-                V4 carry; // the rest of the ray, where its initial momenta were: they are spent
-                carry.x = st.lam; carry.y = st.h_retry; carry.z = rec.z; carry.w = rec.w;
-                const_cast<V4 *>(ic)[q] = carry;
-                __hip_atomic_store(list + slot, (unsigned long long)q + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                real = false;
-                ev = EV_HANDED_OFF;
-            }
-        }
-    }
     if (Integ::GHOST_LANES && wave_any(real)) {
         __builtin_amdgcn_s_setprio(3);
         raised = true;
-        if (!real && (!COOL || ev != EV_HANDED_OFF)) store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
+        if (!real) store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
         uint32_t lead = (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(real));
         uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)wave_iters, (int)lead); // every running lane holds the same count
         bool sync = true;
@@ -663,7 +479,7 @@ __global__ void __launch_bounds__(256, Integ::MIN_WAVES_PER_SIMD) k_kerr_direct(
             }
         }
         wave_iters = it;
-    } else if (!COOL || ev != EV_HANDED_OFF) {
+    } else {
         store_fin<T>(fin0, fin1, q, st.y.r, st.y.th, st.y.ph, st.y.pr, st.y.pth, rec.z, ev, steps);
     }
     meter.end(kstats, wave_iters);
@@ -1255,16 +1071,6 @@ __global__ void __launch_bounds__(256) k_probe_rk4_step(KerrConsts<T> k_in, int 
 #endif // LT_PROBES
 
 #ifndef LT_KERNEL_TEMPLATES_ONLY // (lt_k2_lone.hip: a second translation unit must not define the plain kernels again)
-// The control words of k_kerr_direct's tile queue (QC_*) and the hand-off list, before every launch that uses the queue.
-__global__ void __launch_bounds__(256) k_queue_setup(unsigned long long *__restrict__ ctl, unsigned long long *__restrict__ list,
-                                                     unsigned long long busy0, unsigned long long cfg)
-{
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < QC_WORDS) ctl[i] = i == QC_BUSY ? busy0 : (i == QC_CFG ? cfg : 0ull);
-    if (cfg != 0ull && list)
-        for (int j = i; j < QC_LIST_CAP; j += (int)(gridDim.x * blockDim.x)) list[j] = 0ull;
-}
-
 // Row scatter after the multi-GPU gather: partition rows -> full frame, 16 B per lane where possible.
 __global__ void k_scatter_rows(const uint8_t *__restrict__ part, uint8_t *__restrict__ full, int rows_local,
                                int64_t row_bytes, int row_block, int n_parts, int part_id)
