@@ -191,6 +191,38 @@ def test_length_predictor_matches_its_cpu_twin_and_orders_the_launch():
     assert as_given < 0.70 and by_key >= 0.85
 
 
+def test_length_predictor_keys_do_not_depend_on_the_launch():
+    """The predictor's lanes are refilled from a queue once a batch exceeds what the chip holds at once (k_dense_predict:
+    a lane whose track has ended takes the next one): every track's key must be what it is when the track runs in a
+    wavefront of its own block -- 600 000 tracks through the queue against the same tracks in batches that fit the chip,
+    key for key, and with other refill settings (one lane at a time; chunks that do not divide the batch)."""
+    import os
+    import subprocess
+    import sys
+    a, n = 0.9, 600_000 + 37
+    base = _dense_states(4096, a, 7)
+    rng = np.random.default_rng(11)
+    s0 = base[rng.integers(0, 4096, n)]                      # tracks of every length, in no order
+    s0[:, 5] *= 1.0 + 1e-6 * rng.standard_normal(n)          # (not 4096 distinct keys only)
+    lm = _metric(1.0, a, True)
+    queued = ltrace.dense_predict_lengths(lm, s0)
+    small = np.concatenate([ltrace.dense_predict_lengths(lm, s0[i:i + 65536]) for i in range(0, n, 65536)])
+    assert np.array_equal(queued, small)
+    assert queued.min() > 0 and len(np.unique(queued)) > 50
+    # other hand-out parameters: the environment is read once per process, so in a child
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import ltrace; s0 = np.load(sys.argv[1]); "
+            "np.save(sys.argv[2], ltrace.dense_predict_lengths(ltrace.Metric(ltrace.METRIC_KERR, 0, 1.0, %r), s0))"
+            % (os.path.dirname(ltrace.__file__), a))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "s0.npy"), s0)
+        for refill, chunk in ((1, 64), (64, 48), (8, 1000)):
+            env = dict(os.environ, LT_DENSE_PRED_REFILL=str(refill), LT_DENSE_PRED_CHUNK=str(chunk))
+            out = os.path.join(tmp, f"k_{refill}_{chunk}.npy")
+            subprocess.run([sys.executable, "-c", code, os.path.join(tmp, "s0.npy"), out], check=True, env=env, timeout=300)
+            assert np.array_equal(np.load(out), queued), (refill, chunk)
+
+
 def test_truncation_and_range_end():
     met = metrics.Schwarzschild(1.0)
     s0 = np.array([met.initial_conditions(50.0, np.radians(d)) for d in (8.0, 4.0)])
