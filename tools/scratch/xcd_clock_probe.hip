@@ -7,15 +7,20 @@
 //         workgroup of XCD `cool` additionally times a dependent FMA chain first;
 // mode 1: on XCD `cool` only that one wavefront runs (the chain), every other wavefront there exits at once;
 // mode 2: the chain alone on an otherwise idle chip.
+// mode 3: as mode 0, but the bulk wavefronts of XCD `cool` stop after a quarter of the bulk loop: how fast does the clock of
+//         an XCD answer when its load goes away?  (the chain is timed in 32 segments; printed as MHz per segment)
 // Reported: the chain's clock (s_memtime cycles / s_memrealtime 100 MHz ticks) and time, and the bulk's clocks by XCD.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-struct Rec { unsigned long long cyc, ticks, xcc, kind; }; // kind 1 = chain, 2 = bulk (wave 0 of a workgroup), 0 = idle
+struct Rec { unsigned long long cyc, ticks, xcc, kind; };
+constexpr int SEGS = 32;
+struct Seg { unsigned long long cyc[SEGS], ticks[SEGS], t_end[SEGS]; }; // kind 1 = chain, 2 = bulk (wave 0 of a workgroup), 0 = idle
 
 __device__ __forceinline__ float bulk_loop(float x, int iters)
 {
@@ -41,7 +46,7 @@ __device__ __forceinline__ float chain_loop(float x, int iters)
     return x;
 }
 
-__global__ void __launch_bounds__(256) k_probe(int mode, int cool, int chain_iters, int bulk_iters, Rec *recs, float *sink)
+__global__ void __launch_bounds__(256) k_probe(int mode, int cool, int chain_iters, int bulk_iters, Rec *recs, float *sink, Seg *seg, unsigned long long *t_start)
 {
     const int xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15; // HW_REG_XCC_ID, bits 3:0
     const int wave = threadIdx.x >> 6;
@@ -51,15 +56,22 @@ __global__ void __launch_bounds__(256) k_probe(int mode, int cool, int chain_ite
     Rec r{0, 0, (unsigned long long)xcc, 0};
     if (is_chain) {
         unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
-        acc += chain_loop(x, chain_iters);
-        __builtin_amdgcn_s_waitcnt(0);
+        if (threadIdx.x == 0) t_start[0] = t0;
+        unsigned long long cs = c0, ts = t0;
+        for (int sgm = 0; sgm < SEGS; ++sgm) {
+            acc += chain_loop(x + acc * 1e-30f, chain_iters / SEGS);
+            __builtin_amdgcn_s_waitcnt(0);
+            unsigned long long c = __builtin_amdgcn_s_memtime(), t = __builtin_amdgcn_s_memrealtime();
+            if (threadIdx.x == 0) { seg->cyc[sgm] = c - cs; seg->ticks[sgm] = t - ts; seg->t_end[sgm] = t - t0; }
+            cs = c; ts = t;
+        }
         unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
         r.cyc = c1 - c0; r.ticks = t1 - t0; r.kind = 1;
     } else if (mode == 2 || (mode == 1 && xcc == cool)) {
         // idle
     } else {
         unsigned long long c0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
-        acc += bulk_loop(x, bulk_iters);
+        acc += bulk_loop(x, (mode == 3 && xcc == cool) ? bulk_iters / 4 : bulk_iters);
         __builtin_amdgcn_s_waitcnt(0);
         unsigned long long c1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
         r.cyc = c1 - c0; r.ticks = t1 - t0; r.kind = 2;
@@ -76,20 +88,23 @@ int main(int argc, char **argv)
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int grid = prop.multiProcessorCount * per_cu;
-    Rec *d_recs; float *d_sink;
+    Rec *d_recs; float *d_sink; Seg *d_seg; unsigned long long *d_t0;
     CHECK(hipMalloc(&d_recs, sizeof(Rec) * grid));
     CHECK(hipMalloc(&d_sink, 64));
+    CHECK(hipMalloc(&d_seg, sizeof(Seg)));
+    CHECK(hipMalloc(&d_t0, 8));
+    Seg seg;
     std::vector<Rec> recs(grid);
     printf("# %s, %d CUs, grid %d x 256 (%d workgroups per CU), chain %d x 64 dependent FMAs, bulk %d x 64 FMAs per lane\n", prop.name,
            prop.multiProcessorCount, grid, per_cu, chain_iters, bulk_iters);
     for (int rep = 0; rep < 2; ++rep)
-        for (int mode = 0; mode < 3; ++mode)
+        for (int mode = 0; mode < 4; ++mode)
             for (int cool : {0, 3}) {
                 CHECK(hipMemset(d_recs, 0, sizeof(Rec) * grid));
                 hipEvent_t e0, e1;
                 CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
                 CHECK(hipEventRecord(e0, 0));
-                k_probe<<<grid, 256>>>(mode, cool, chain_iters, bulk_iters, d_recs, d_sink);
+                k_probe<<<grid, 256>>>(mode, cool, chain_iters, bulk_iters, d_recs, d_sink, d_seg, d_t0);
                 CHECK(hipEventRecord(e1, 0));
                 CHECK(hipDeviceSynchronize());
                 float ms = 0;
@@ -107,6 +122,12 @@ int main(int argc, char **argv)
                        chain_mhz, chain_ms);
                 for (int x = 0; x < 8; ++x) printf(" %s", bn[x] ? (std::to_string((int)(bc[x] / bt[x] * 100.0))).c_str() : "-");
                 printf("  (workgroups whose XCC_ID != b %% 8: %d)\n", mism);
+                if (mode == 3 || (mode == 0 && rep == 1)) {
+                    CHECK(hipMemcpy(&seg, d_seg, sizeof(Seg), hipMemcpyDeviceToHost));
+                    printf("    chain MHz by segment (segment end, ms):");
+                    for (int g = 0; g < SEGS; ++g) printf(" %d(%.2f)", (int)((double)seg.cyc[g] / seg.ticks[g] * 100.0), seg.t_end[g] / 1e5);
+                    printf("\n");
+                }
             }
     return 0;
 }
