@@ -98,7 +98,7 @@ def parse(argv=None):
     ap.add_argument("--balance", choices=["cyclic", "cost", "auto"], default="auto",
                     help="row blocks -> ranks: block-cyclic, or cost-weighted from one untimed frame's step counts "
                          "(sharding.balance_blocks: the rank that owns the longest ray gets less of the bulk; DESIGN.md 5.1: "
-                         "3.87 against 4.13 ms per rank of 8, emulated on one GPU). auto (default) IS block-cyclic: the "
+                         "3.82 against 4.03 ms per rank of 8, emulated on one GPU). auto (default) IS block-cyclic: the "
                          "cost-weighted table has never run over RCCL on real devices, so it is opt-in until a hardware run "
                          "confirms the gain; the JSON line records which partition the timed region ran")
     ap.add_argument("--owner-file", default=None, help="(.npy, uint16) a row-block owner table to use as is (emulated ranks)")
@@ -413,7 +413,7 @@ def main(argv=None):
     bid = ltrace.build_id()
     main_stream = torch.cuda.current_stream(dev)
 
-    # ---- row blocks -> ranks.  `auto` IS block-cyclic: the cost-weighted table (3.87 against 4.13 ms for the
+    # ---- row blocks -> ranks.  `auto` IS block-cyclic: the cost-weighted table (3.82 against 4.03 ms for the
     # slowest rank of 8, emulated on one GPU) has never run over RCCL on real devices, so it stays opt-in (--balance cost)
     # until a hardware run confirms it; and when asked for, any failure on any rank sends ALL ranks back to block-cyclic.
     owner, balance_used = None, "cyclic"
